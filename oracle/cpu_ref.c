@@ -1,0 +1,333 @@
+/*
+ * cpu_ref.c -- CPU restatement of versalignLib's Default (scalar) AlignmentKernel.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP backend.
+ * Nothing in the product path (versalignlib_amd/, libHIPKernel.so) may call, link
+ * or import it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg do.  It is a from-scratch restatement of the reference algorithm, pinned
+ * against the compiled reference kernels (oracle/_ref, built by oracle/Makefile
+ * from /root/reference where that tree exists) through tests/golden/ fixtures.
+ *
+ * Reference semantics followed (paths relative to the reference checkout):
+ *   base classes ........ src/Kernels/default/DefaultKernel.h:43-60  (char_to_score)
+ *   substitution table .. src/Kernels/default/DefaultKernel.h:83-97  (base_score)
+ *   SW score ............ src/Kernels/default/DefaultKernel.cpp:83-138
+ *   NW-variant score .... src/Kernels/default/DefaultKernel.cpp:140-202
+ *   SW fill + end cell .. src/Kernels/default/DefaultKernel.cpp:204-280
+ *   NW fill + end cell .. src/Kernels/default/DefaultKernel.cpp:282-389
+ *   SW / NW traceback ... src/Kernels/default/DefaultKernel.cpp:391-456, 458-525
+ *
+ * Deliberate, documented differences from the Default kernel's *outputs*:
+ *   - scores are returned as full int16 (Default stores only the low byte,
+ *     DefaultKernel.cpp:137,199; SSE/AVX/OpenCL store the full short);
+ *   - alignment rows are zero-filled before readStart and carry '\0' at index
+ *     R+F-1 for SW too (Default leaves those bytes uninitialised for SW);
+ *   - bytes >= 0x80 map to class 0 (the reference indexes a table with a signed
+ *     char there, which is undefined).
+ *
+ * The affine-gap (Gotoh) functions at the bottom are an EXTENSION with no
+ * reference counterpart ("parity unpinned by the reference"); they are pinned
+ * only by the identity affine(open == extend == g) == linear(g).
+ *
+ * Data layout for every entry point: reads = n*R bytes, pair-major contiguous;
+ * refs = n*F bytes likewise; each sequence exactly R / F bytes, short ones
+ * right-padded with '\0' (the reference host's pad(), src/util/versalignUtil.cpp:17-33).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PTR_START 0
+#define PTR_DIAG  1
+#define PTR_UP    2
+#define PTR_LEFT  3
+
+typedef struct {
+    int32_t match, mismatch, gap_read, gap_ref;                 /* linear model (reference) */
+    int32_t open_read, ext_read, open_ref, ext_ref;             /* affine extension         */
+} vref_scoring;
+
+/* ---- base classes: A/a 1, T/t 2, C/c 3, G/g 4, N/n 5, everything else 0 ---- */
+static uint8_t g_class[256];
+static int g_class_ready = 0;
+
+static void class_init(void) {
+    if (g_class_ready) return;
+    memset(g_class, 0, sizeof g_class);
+    g_class['A'] = g_class['a'] = 1;
+    g_class['T'] = g_class['t'] = 2;
+    g_class['C'] = g_class['c'] = 3;
+    g_class['G'] = g_class['g'] = 4;
+    g_class['N'] = g_class['n'] = 5;
+    g_class_ready = 1;
+}
+
+/* 6x6 substitution table: 0 whenever either class is 0 or 5 */
+static void subst_init(const vref_scoring *sc, int16_t tab[6][6]) {
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            int16_t v = 0;
+            if (a >= 1 && a <= 4 && b >= 1 && b <= 4)
+                v = (int16_t)(a == b ? sc->match : sc->mismatch);
+            tab[a][b] = v;
+        }
+}
+
+static inline int16_t max16(int16_t a, int16_t b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------ scores */
+
+static int16_t sw_score_one(const uint8_t *read, const uint8_t *ref, int R, int F,
+                            int16_t tab[6][6], int16_t gr, int16_t gf, int16_t *rows) {
+    int16_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));
+    int16_t best = 0;
+    for (int i = 0; i < R; ++i) {
+        const int16_t *srow = tab[g_class[read[i]]];
+        for (int j = 0; j < F; ++j) {
+            int16_t up = prev[j + 1], left = cur[j];
+            int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
+            int16_t h = max16((int16_t)(up + gf), max16((int16_t)(left + gr), max16(diag, 0)));
+            cur[j + 1] = h;
+            best = max16(best, h);
+        }
+        int16_t *t = prev; prev = cur; cur = t;
+    }
+    return best;
+}
+
+static int16_t nw_score_one(const uint8_t *read, const uint8_t *ref, int R, int F,
+                            int16_t tab[6][6], int16_t gr, int16_t gf, int16_t *rows) {
+    int16_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));   /* row 0 and column 0 stay 0 */
+    int16_t best = 0;
+    for (int i = 0; i < R; ++i) {
+        const int16_t *srow = tab[g_class[read[i]]];
+        for (int j = 0; j < F; ++j) {
+            int16_t up = prev[j + 1], left = cur[j];
+            int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
+            cur[j + 1] = max16((int16_t)(up + gf), max16((int16_t)(left + gr), diag));
+        }
+        best = max16(best, cur[F]);                           /* last column, every row */
+        int16_t *t = prev; prev = cur; cur = t;
+    }
+    for (int j = 0; j <= F; ++j) best = max16(best, prev[j]); /* last computed row      */
+    return best;
+}
+
+/* opt: 0 = Smith-Waterman, 1 = reference's Needleman-Wunsch variant */
+int vref_score(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+               const vref_scoring *sc, int16_t *scores, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;                            /* reference: silent no-op */
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int16_t gr = (int16_t)sc->gap_read, gf = (int16_t)sc->gap_ref;
+    const int alg = opt & 0xF;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t *rows = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            scores[p] = alg == 0 ? sw_score_one(rd, rf, R, F, tab, gr, gf, rows)
+                                 : nw_score_one(rd, rf, R, F, tab, gr, gf, rows);
+        }
+        free(rows);
+    }
+    return n;
+}
+
+/* -------------------------------------------------------------- alignments */
+
+/* SW fill: pointer priority START(cell==0) > DIAG > UP > LEFT; end cell = first
+ * strictly greater cell in row-major order (DefaultKernel.cpp:238-256).          */
+static void sw_fill(const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                    int16_t gr, int16_t gf, int16_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
+    int16_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));
+    int16_t best = 0; int bi = 0, bj = 0;
+    for (int i = 0; i < R; ++i) {
+        const int16_t *srow = tab[g_class[read[i]]];
+        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
+        for (int j = 0; j < F; ++j) {
+            int16_t up = prev[j + 1], left = cur[j];
+            int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
+            int16_t h = max16((int16_t)(up + gf), max16((int16_t)(left + gr), max16(diag, 0)));
+            cur[j + 1] = h;
+            uint8_t p = PTR_START;
+            if (h == 0) p = PTR_START;
+            else if (h == diag) p = PTR_DIAG;
+            else if (h == up + gf) p = PTR_UP;
+            else if (h == left + gr) p = PTR_LEFT;
+            prow[j + 1] = p;
+            if (h > best) { best = h; bi = i; bj = j; }
+        }
+        int16_t *t = prev; prev = cur; cur = t;
+    }
+    *end_i = bi; *end_j = bj;
+}
+
+/* NW-variant fill: column 0 = (i+1)*gap_ref with UP, row 0 = 0 with START, priority
+ * DIAG > UP > LEFT, end cell from the first-invalid-character bookkeeping
+ * (DefaultKernel.cpp:285-318, 340-355, 381-387).                                  */
+static void nw_fill(const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                    int16_t gr, int16_t gf, int16_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
+    int16_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));
+    int16_t last_read = (int16_t)(R - 1), last_ref = (int16_t)(F - 1);
+    int16_t row_best = INT16_MIN, row_arg = 0, snap_arg = -1;
+    for (int i = 0; i < R; ++i) {
+        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
+        prow[0] = PTR_UP;
+        cur[0] = (int16_t)((i + 1) * gf);
+        if (last_read == R - 1 && g_class[read[i]] == 0) last_read = (int16_t)(i - 1);
+        if (last_read + 1 == i) snap_arg = row_arg;           /* argmax of the previous row */
+        row_best = cur[0]; row_arg = 0;
+        const int16_t *srow = tab[g_class[read[i]]];
+        for (int j = 0; j < F; ++j) {
+            int16_t up = prev[j + 1], left = cur[j];
+            int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
+            int16_t h = max16((int16_t)(up + gf), max16((int16_t)(left + gr), diag));
+            cur[j + 1] = h;
+            uint8_t p = PTR_START;
+            if (h == diag) p = PTR_DIAG;
+            else if (h == up + gf) p = PTR_UP;
+            else if (h == left + gr) p = PTR_LEFT;
+            if (last_ref == F - 1 && g_class[ref[j]] == 0) last_ref = (int16_t)(j - 1);
+            if (h > row_best) { row_best = h; row_arg = (int16_t)j; }
+            prow[j + 1] = p;
+        }
+        int16_t *t = prev; prev = cur; cur = t;
+    }
+    if (snap_arg < 0) snap_arg = row_arg;
+    *end_i = last_read;
+    *end_j = last_ref < snap_arg ? last_ref : snap_arg;
+}
+
+static void traceback(const uint8_t *read, const uint8_t *ref, int R, int F, const uint8_t *ptr,
+                      int rp, int fp, uint8_t *row_read, uint8_t *row_ref, int16_t idx[4]) {
+    const int AL = R + F;
+    memset(row_read, 0, (size_t)AL);
+    memset(row_ref, 0, (size_t)AL);
+    int k = AL - 2;
+    uint8_t p = ptr[(size_t)(rp + 1) * (F + 1) + fp + 1];
+    while (p != PTR_START) {
+        if (p == PTR_UP)        { row_ref[k] = '-';      row_read[k] = read[rp--]; }
+        else if (p == PTR_LEFT) { row_read[k] = '-';     row_ref[k] = ref[fp--];   }
+        else                    { row_read[k] = read[rp--]; row_ref[k] = ref[fp--]; }
+        p = ptr[(size_t)(rp + 1) * (F + 1) + fp + 1];
+        --k;
+    }
+    idx[0] = (int16_t)(k + 1);      /* readStart */
+    idx[1] = (int16_t)(AL - 1);     /* readEnd   */
+    idx[2] = (int16_t)(k + 1);      /* refStart  */
+    idx[3] = (int16_t)(AL - 1);     /* refEnd    */
+}
+
+/* rows: n * 2 * (R+F) bytes (read row then ref row per pair); idx: n * 4 int16
+ * (readStart, readEnd, refStart, refEnd).                                        */
+int vref_align(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+               const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int16_t gr = (int16_t)sc->gap_read, gf = (int16_t)sc->gap_ref;
+    const int alg = opt & 0xF, AL = R + F;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t *rows = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(F + 1));
+        uint8_t *ptr = (uint8_t *)malloc((size_t)(R + 1) * (F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(ptr, PTR_START, (size_t)(R + 1) * (F + 1));
+            int ei, ej;
+            if (alg == 0) sw_fill(rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
+            else          nw_fill(rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
+            traceback(rd, rf, R, F, ptr, ei, ej, rows_out + (size_t)p * 2 * AL,
+                      rows_out + (size_t)p * 2 * AL + AL, idx_out + (size_t)p * 4);
+        }
+        free(ptr);
+        free(rows);
+    }
+    return n;
+}
+
+/* ------------------------------------------- affine-gap extension (Gotoh) */
+/* Not in the reference.  open_* = cost of the FIRST gap base, ext_* = cost of each
+ * further one, so open == ext == g reproduces the linear model exactly.
+ *   E(i,j) = max(E(i,j-1) + ext_read, H(i,j-1) + open_read)      gap in the read (LEFT)
+ *   F(i,j) = max(F(i-1,j) + ext_ref,  H(i-1,j) + open_ref)       gap in the ref  (UP)
+ *   H(i,j) = max([0,] H(i-1,j-1) + S, E(i,j), F(i,j))
+ * Borders follow the reference score kernels: H(0,*) = H(*,0) = 0; E(*,0) and
+ * F(0,*) are "minus infinity" (NEG_INF, never selected).  NW result as in the
+ * linear variant: max(0, last column, last row).                                  */
+#define NEG_INF ((int16_t)-16384)
+
+static inline int16_t sat_add(int16_t a, int16_t b) {
+    int v = (int)a + (int)b;
+    return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+}
+
+int vref_score_affine(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                      const vref_scoring *sc, int16_t *scores, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int16_t oR = (int16_t)sc->open_read, eR = (int16_t)sc->ext_read;
+    const int16_t oF = (int16_t)sc->open_ref,  eF = (int16_t)sc->ext_ref;
+    const int alg = opt & 0xF;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t *H = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
+        int16_t *Fv = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            for (int j = 0; j <= F; ++j) { H[j] = 0; Fv[j] = NEG_INF; }
+            int16_t best = 0;
+            for (int i = 0; i < R; ++i) {
+                const int16_t *srow = tab[g_class[rd[i]]];
+                int16_t hdiag = H[0];           /* H(i-1, 0) */
+                int16_t hleft = 0;              /* H(i, 0)   */
+                int16_t e = NEG_INF;
+                for (int j = 0; j < F; ++j) {
+                    int16_t hup = H[j + 1];
+                    e = max16(sat_add(e, eR), sat_add(hleft, oR));
+                    int16_t f = max16(sat_add(Fv[j + 1], eF), sat_add(hup, oF));
+                    int16_t h = max16(max16((int16_t)(hdiag + srow[g_class[rf[j]]]), e), f);
+                    if (alg == 0) { h = max16(h, 0); best = max16(best, h); }
+                    Fv[j + 1] = f;
+                    hdiag = hup;
+                    H[j + 1] = h;
+                    hleft = h;
+                }
+                H[0] = 0;
+                if (alg == 1) best = max16(best, H[F]);
+            }
+            if (alg == 1) for (int j = 0; j <= F; ++j) best = max16(best, H[j]);
+            scores[p] = best;
+        }
+        free(Fv);
+        free(H);
+    }
+    return n;
+}
+
+int vref_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

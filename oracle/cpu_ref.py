@@ -1,0 +1,106 @@
+"""ctypes view of oracle/libcpuref.so -- the CPU parity checker.
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never from versalignlib_amd (the product path).
+The C source (oracle/cpu_ref.c) cites the reference lines it restates.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcpuref.so")
+REF_DIR = os.path.join(_HERE, "_ref")
+
+
+class Scoring(ctypes.Structure):
+    """Mirror of vref_scoring: linear model (reference) + affine extension."""
+
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "match", "mismatch", "gap_read", "gap_ref",
+        "open_read", "ext_read", "open_ref", "ext_ref")]
+
+    @classmethod
+    def make(cls, match=2, mismatch=-1, gap_read=-3, gap_ref=-3,
+             open_read=None, ext_read=None, open_ref=None, ext_ref=None):
+        return cls(match, mismatch, gap_read, gap_ref,
+                   gap_read if open_read is None else open_read,
+                   gap_read if ext_read is None else ext_read,
+                   gap_ref if open_ref is None else open_ref,
+                   gap_ref if ext_ref is None else ext_ref)
+
+
+def build(force=False):
+    """Compile libcpuref.so (and oracle/_ref when the reference tree is present)."""
+    src = os.path.join(_HERE, "cpu_ref.c")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))
+    if force or stale or not os.path.isdir(REF_DIR):
+        subprocess.run(["make", "-C", _HERE, "--no-print-directory"], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        i16p = ctypes.POINTER(ctypes.c_int16)
+        sp = ctypes.POINTER(Scoring)
+        for name in ("vref_score", "vref_score_affine"):
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, i16p, ctypes.c_int]
+        L.vref_align.restype = ctypes.c_int
+        L.vref_align.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, u8p, i16p, ctypes.c_int]
+        L.vref_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _check(reads, refs):
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    refs = np.ascontiguousarray(refs, dtype=np.uint8)
+    assert reads.ndim == 2 and refs.ndim == 2 and reads.shape[0] == refs.shape[0]
+    return reads, refs
+
+
+def score(opt, reads, refs, scoring=None, threads=1, affine=False):
+    """reads [n,R] uint8, refs [n,F] uint8 -> int16 [n] (full-width scores)."""
+    reads, refs = _check(reads, refs)
+    sc = scoring or Scoring.make()
+    n, R = reads.shape
+    F = refs.shape[1]
+    out = np.zeros(n, dtype=np.int16)
+    fn = lib().vref_score_affine if affine else lib().vref_score
+    fn(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc),
+       out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
+    return out
+
+
+def align(opt, reads, refs, scoring=None, threads=1):
+    """-> rows uint8 [n,2,R+F] (zero before start, NUL at R+F-1), idx int16 [n,4]."""
+    reads, refs = _check(reads, refs)
+    sc = scoring or Scoring.make()
+    n, R = reads.shape
+    F = refs.shape[1]
+    rows = np.zeros((n, 2, R + F), dtype=np.uint8)
+    idx = np.zeros((n, 4), dtype=np.int16)
+    lib().vref_align(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), _u8(rows),
+                     idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
+    return rows, idx
+
+
+def max_threads():
+    return lib().vref_max_threads()

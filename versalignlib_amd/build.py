@@ -1,0 +1,76 @@
+"""In-tree builds of the two shared objects this package ships.
+
+  lib/libHIPKernel.so .... the versalignLib plugin for MI355X (hipcc, gfx950 only)
+  lib/libvalignhost.so ... the host side of the plugin protocol behind a flat C API (g++)
+
+Both land under versalignlib_amd/lib/ (git-ignored, shipped to the GPU box by gpurun).
+hipcc cross-compiles gfx950 without a GPU, so build_all() works on a CPU-only machine.
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_PLUGIN = os.path.join(LIB, "libHIPKernel.so")
+HOST_LIB = os.path.join(LIB, "libvalignhost.so")
+
+HIP_SOURCES = ["hip_plugin.hip"]
+HIP_DEPS = ["hip_plugin.hip", "dp_kernels.hip.h", "hip_engine.hip.h"]
+HOST_SOURCES = ["valign_host.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), proc.stdout))
+    return proc.stdout
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP plugin cannot be built")
+
+
+def build_host(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(INCLUDE, h) for h in ("valign_host.h", "versalign_plugin_abi.h")]
+    if force or _newer(HOST_LIB, deps):
+        _run(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", "-pthread",
+              "-I" + INCLUDE] + srcs + ["-o", HOST_LIB, "-ldl"])
+    return HOST_LIB
+
+
+def build_hip(force=False, extra_flags=()):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = [os.path.join(CSRC, s) for s in HIP_DEPS] + [
+        os.path.join(INCLUDE, h) for h in ("valign_hip.h", "versalign_plugin_abi.h")]
+    if force or _newer(HIP_PLUGIN, deps):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
+              "-pthread", "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
+             + list(extra_flags) + srcs + ["-o", HIP_PLUGIN])
+    return HIP_PLUGIN
+
+
+def build_all(force=False):
+    return build_host(force), build_hip(force)
+
+
+if __name__ == "__main__":
+    import sys
+    print("\n".join(build_all(force="--force" in sys.argv)))

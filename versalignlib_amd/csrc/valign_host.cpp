@@ -1,0 +1,362 @@
+// valign_host.cpp -- host side of the versalignLib plugin protocol behind a flat C API.
+// See include/valign_host.h for the contract and the reference call sites mirrored.
+#include "valign_host.h"
+#include "versalign_plugin_abi.h"
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <chrono>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const std::string &msg) {
+    g_error = msg;
+    return -1;
+}
+
+// Key -> int store injected into the plugin.  Counterpart of the reference host's
+// CustomParameters (src/impl/CustomParameters.h): same defaults, same "unknown key"
+// behaviour (has_key false; param_int throws a C string).
+class HostParameters : public AlignmentParameters {
+public:
+    HostParameters() {
+        values["score_match"] = 2;
+        values["score_mismatch"] = -1;
+        values["score_gap_read"] = -3;
+        values["score_gap_ref"] = -3;
+        values["num_threads"] = 1;
+    }
+    int param_int(char const *const key) override {
+        auto it = values.find(key);
+        if (it == values.end()) {
+            scratch = std::string("Unknown int parameter: ") + key;
+            throw scratch.c_str();
+        }
+        return it->second;
+    }
+    bool has_key(char const *const key) override { return values.count(key) != 0; }
+
+    std::map<std::string, int> values;
+
+private:
+    std::string scratch;
+};
+
+// Thread-safe sink (the reference's CustomLogger shares one stringstream and is not).
+class HostLogger : public AlignmentLogger {
+public:
+    void log(int const level, char const *const main, char const *const msg,
+             size_t const &arg_num = 0, ...) override {
+        const char *sev = "ERROR";
+        if (level == 0) sev = "INFO";
+        else if (level == 1) sev = "WARNING";
+        else if (level == 3) sev = "DRASTIC";
+        std::string out = std::string(sev) + "\t[" + (main ? main : "") + "]\t" + (msg ? msg : "") + "\n";
+        if (arg_num > 0) {
+            va_list args;
+            va_start(args, arg_num);
+            for (size_t i = 0; i < arg_num; ++i) {
+                const char *extra = va_arg(args, const char *);
+                out += std::string(sev) + "\t[" + (main ? main : "") + "]\t" + (extra ? extra : "") + "\n";
+            }
+            va_end(args);
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (echo) fputs(out.c_str(), stderr);
+        if (lines.size() < (1u << 20)) lines += out;
+    }
+    std::mutex mu;
+    std::string lines;
+    bool echo = false;
+};
+
+}  // namespace
+
+struct vh_plugin {
+    void *dl = nullptr;
+    fp_load_alignment_kernel spawn = nullptr;
+    fp_delete_alignment_kernel destroy = nullptr;
+    void (*set_params)(AlignmentParameters *) = nullptr;
+    void (*set_log)(AlignmentLogger *) = nullptr;
+    AlignmentKernel *kernel = nullptr;
+    HostParameters params;
+    HostLogger logger;
+};
+
+namespace {
+
+bool lengths(vh_plugin *p, int *R, int *F) {
+    auto r = p->params.values.find("read_length");
+    auto f = p->params.values.find("ref_length");
+    if (r == p->params.values.end() || f == p->params.values.end()) return false;
+    *R = r->second;
+    *F = f->second;
+    return *R >= 0 && *F >= 0;
+}
+
+template <typename Fn>
+int guarded(const char *what, Fn &&fn) {
+    try {
+        fn();
+        return 0;
+    } catch (const char *msg) {
+        return fail(std::string(what) + ": " + (msg ? msg : "(null)"));
+    } catch (const std::exception &e) {
+        return fail(std::string(what) + ": " + e.what());
+    } catch (...) {
+        return fail(std::string(what) + ": unknown exception");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vh_last_error(void) { return g_error.c_str(); }
+
+vh_plugin *vh_open(const char *so_path) {
+    void *dl = dlopen(so_path, RTLD_LAZY);
+    if (!dl) {
+        const char *why = dlerror();
+        fail(std::string("dlopen failed: ") + (why ? why : so_path));
+        return nullptr;
+    }
+    vh_plugin *p = new (std::nothrow) vh_plugin();
+    if (!p) {
+        dlclose(dl);
+        fail("out of memory");
+        return nullptr;
+    }
+    p->dl = dl;
+    p->spawn = (fp_load_alignment_kernel)dlsym(dl, VERSALIGN_SYM_SPAWN);
+    p->destroy = (fp_delete_alignment_kernel)dlsym(dl, VERSALIGN_SYM_DELETE);
+    p->set_params = (void (*)(AlignmentParameters *))dlsym(dl, VERSALIGN_SYM_SET_PARAMS);
+    p->set_log = (void (*)(AlignmentLogger *))dlsym(dl, VERSALIGN_SYM_SET_LOGGER);
+    if (!p->spawn || !p->destroy || !p->set_params || !p->set_log) {
+        fail(std::string("plugin lacks one of the four versalignLib symbols: ") + so_path);
+        dlclose(dl);
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+int vh_set_param(vh_plugin *p, const char *key, int value) {
+    if (!p || !key) return fail("null argument");
+    p->params.values[key] = value;
+    return 0;
+}
+
+int vh_unset_param(vh_plugin *p, const char *key) {
+    if (!p || !key) return fail("null argument");
+    p->params.values.erase(key);
+    return 0;
+}
+
+int vh_reapply_params(vh_plugin *p) {
+    if (!p) return fail("null plugin");
+    p->set_params(&p->params);
+    return 0;
+}
+
+int vh_spawn(vh_plugin *p) {
+    if (!p) return fail("null plugin");
+    if (p->kernel) return fail("kernel already spawned");
+    p->set_params(&p->params);
+    p->set_log(&p->logger);
+    int rc = guarded("spawn_alignment_kernel", [&] { p->kernel = p->spawn(); });
+    if (rc == 0 && !p->kernel) return fail("spawn_alignment_kernel returned null");
+    return rc;
+}
+
+int vh_score(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs,
+             int16_t *scores) {
+    if (!p || !p->kernel) return fail("kernel not spawned");
+    int R, F;
+    if (!lengths(p, &R, &F)) return fail("read_length / ref_length not set");
+    if (n < 0) return fail("negative pair count");
+    std::vector<const char *> rp((size_t)n), fp((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        rp[i] = (const char *)reads + (size_t)i * R;
+        fp[i] = (const char *)refs + (size_t)i * F;
+    }
+    return guarded("score_alignments",
+                   [&] { p->kernel->score_alignments(opt, n, rp.data(), fp.data(), scores); });
+}
+
+int vh_score_scattered(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs,
+                       int16_t *scores, double *seconds_out) {
+    if (!p || !p->kernel) return fail("kernel not spawned");
+    int R, F;
+    if (!lengths(p, &R, &F)) return fail("read_length / ref_length not set");
+    if (n < 0) return fail("negative pair count");
+    std::vector<char *> rp((size_t)n), fp((size_t)n);
+    for (int i = 0; i < n; ++i) {          // one heap block per sequence, as pad() leaves them
+        rp[i] = new char[R > 0 ? R : 1];
+        fp[i] = new char[F > 0 ? F : 1];
+        memcpy(rp[i], reads + (size_t)i * R, (size_t)R);
+        memcpy(fp[i], refs + (size_t)i * F, (size_t)F);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = guarded("score_alignments", [&] {
+        p->kernel->score_alignments(opt, n, rp.data(), fp.data(), scores);
+    });
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+    for (int i = 0; i < n; ++i) {
+        delete[] rp[i];
+        delete[] fp[i];
+    }
+    return rc;
+}
+
+int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs,
+             uint8_t *rows, int16_t *idx, int normalise) {
+    if (!p || !p->kernel) return fail("kernel not spawned");
+    int R, F;
+    if (!lengths(p, &R, &F)) return fail("read_length / ref_length not set");
+    if (n < 0) return fail("negative pair count");
+    const int AL = R + F;
+    std::vector<const char *> rp((size_t)n), fp((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        rp[i] = (const char *)reads + (size_t)i * R;
+        fp[i] = (const char *)refs + (size_t)i * F;
+    }
+    Alignment *alns = new Alignment[(size_t)n]();     // value-initialised, as main.cpp:123
+    int rc = guarded("compute_alignments",
+                     [&] { p->kernel->compute_alignments(opt, n, rp.data(), fp.data(), alns); });
+    if (rc == 0) {
+        for (int i = 0; i < n; ++i) {
+            uint8_t *rr = rows + (size_t)i * 2 * AL, *fr = rr + AL;
+            const Alignment &a = alns[i];
+            if (!a.read || !a.ref) {          // opt with no algorithm: plugin left it untouched
+                memset(rr, 0, (size_t)2 * AL);
+                idx[4 * i] = idx[4 * i + 1] = idx[4 * i + 2] = idx[4 * i + 3] = 0;
+                continue;
+            }
+            memcpy(rr, a.read, (size_t)AL);
+            memcpy(fr, a.ref, (size_t)AL);
+            idx[4 * i + 0] = a.readStart;
+            idx[4 * i + 1] = a.readEnd;
+            idx[4 * i + 2] = a.refStart;
+            idx[4 * i + 3] = a.refEnd;
+            if (normalise) {
+                int s = a.readStart;
+                if (s < 0) s = 0;
+                if (s > AL) s = AL;
+                memset(rr, 0, (size_t)s);
+                memset(fr, 0, (size_t)s);
+                if (AL > 0) rr[AL - 1] = fr[AL - 1] = 0;
+            }
+        }
+    }
+    delete[] alns;
+    return rc;
+}
+
+void vh_close(vh_plugin *p) {
+    if (!p) return;
+    if (p->kernel) {
+        guarded("delete_alignment_kernel", [&] { p->destroy(p->kernel); });
+        p->kernel = nullptr;
+    }
+    if (p->dl) dlclose(p->dl);
+    delete p;
+}
+
+int vh_drain_log(vh_plugin *p, char *buf, int cap) {
+    if (!p || !buf || cap <= 0) return 0;
+    std::lock_guard<std::mutex> lock(p->logger.mu);
+    size_t n = p->logger.lines.size();
+    if (n > (size_t)cap - 1) n = (size_t)cap - 1;
+    memcpy(buf, p->logger.lines.data(), n);
+    buf[n] = 0;
+    p->logger.lines.clear();
+    return (int)n;
+}
+
+void vh_log_to_stderr(vh_plugin *p, int on) {
+    if (p) p->logger.echo = on != 0;
+}
+
+// ---- host data formats ----
+
+int vh_parse_fasta(const char *path, char **blob, int *count) {
+    if (!path || !blob || !count) return fail("null argument");
+    std::ifstream in(path);
+    if (!in.good()) return fail(std::string("cannot open ") + path);
+    // Same acceptance rules as the reference parser: a record starts at '>' and ends at
+    // the next '>' or blank line; a sequence line containing a space discards the record;
+    // only complete lines (terminated by '\n') are consumed.
+    std::vector<std::string> seqs;
+    std::string line, name, content;
+    while (std::getline(in, line).good()) {
+        if (line.empty() || line[0] == '>') {
+            if (!name.empty()) {
+                seqs.push_back(content);
+                name.clear();
+            }
+            if (!line.empty()) name = line.substr(1);
+            content.clear();
+        } else if (!name.empty()) {
+            if (line.find(' ') != std::string::npos) {
+                name.clear();
+                content.clear();
+            } else {
+                content += line;
+            }
+        }
+    }
+    if (!name.empty()) seqs.push_back(content);
+    size_t total = 0;
+    for (auto &s : seqs) total += strlen(s.c_str()) + 1;   // strdup semantics: stop at NUL
+    char *out = (char *)malloc(total ? total : 1);
+    if (!out) return fail("out of memory");
+    size_t off = 0;
+    for (auto &s : seqs) {
+        size_t len = strlen(s.c_str());
+        memcpy(out + off, s.c_str(), len + 1);
+        off += len + 1;
+    }
+    *blob = out;
+    *count = (int)seqs.size();
+    return 0;
+}
+
+int vh_pad(const char *blob, int count, char fill, uint8_t **out, int *length) {
+    if (!blob || !out || !length || count < 0) return fail("bad argument");
+    size_t longest = 0;
+    const char *s = blob;
+    for (int i = 0; i < count; ++i) {
+        size_t len = strlen(s);
+        if (len > longest) longest = len;
+        s += len + 1;
+    }
+    uint8_t *buf = (uint8_t *)malloc(longest * (size_t)count ? longest * (size_t)count : 1);
+    if (!buf) return fail("out of memory");
+    s = blob;
+    for (int i = 0; i < count; ++i) {
+        size_t len = strlen(s);
+        uint8_t *dst = buf + (size_t)i * longest;
+        memcpy(dst, s, len);
+        memset(dst + len, (unsigned char)fill, longest - len);
+        s += len + 1;
+    }
+    *out = buf;
+    *length = (int)longest;
+    return 0;
+}
+
+void vh_free(void *ptr) { free(ptr); }
+
+}  // extern "C"
