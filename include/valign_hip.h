@@ -1,0 +1,93 @@
+/*
+ * valign_hip.h -- entry points of libHIPKernel.so, the MI355X (gfx950) backend.
+ *
+ * (1) The versalignLib plugin boundary -- what the reference host binds with dlsym()
+ *     (src/util/versalignUtil.cpp:35-76, src/impl/main.cpp:217-238).  Same four symbols
+ *     and the same behaviour as src/Kernels/default/DefaultKernel_dllexport.cpp:18-42:
+ *
+ *       AlignmentKernel *spawn_alignment_kernel();
+ *       void set_parameters(AlignmentParameters *);
+ *       void set_logger(AlignmentLogger *);
+ *       void delete_alignment_kernel(AlignmentKernel *);
+ *
+ *     The spawned object implements AlignmentKernel::score_alignments and
+ *     ::compute_alignments (include/AlignmentKernel.h:40-43, restated in
+ *     versalign_plugin_abi.h).  Required parameter keys are the reference's six
+ *     (DefaultKernel.h:70-75); a missing one makes spawn throw the same C string.
+ *     Optional keys, probed with has_key (a reference host simply lacks them):
+ *       score_gap_open_read / score_gap_extend_read /
+ *       score_gap_open_ref  / score_gap_extend_ref ... affine-gap extension (all four)
+ *       hip_device ...................................... device ordinal (default 0)
+ *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
+ *
+ * (2) A flat C view of the same engine for callers that already hold the batch in
+ *     device memory (bench.py, multi-GPU sharding): plain pointers and sizes only.
+ *     These replace nothing in the reference -- its OpenCL backend is the closest
+ *     precedent (gather -> contiguous pair-major buffers -> device,
+ *     src/Kernels/OpenCL/OpenCLKernel.cpp:57-108) -- and take exactly the contiguous
+ *     buffers that backend builds internally.
+ *
+ * All flat functions return 0 on success, non-zero on failure (message through
+ * valign_hip_last_error()).  There is no CPU fallback anywhere in this library.
+ */
+#ifndef VALIGN_HIP_H
+#define VALIGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) plugin boundary (C++ types from versalign_plugin_abi.h) ---- */
+#ifdef __cplusplus
+class AlignmentKernel;
+class AlignmentParameters;
+class AlignmentLogger;
+AlignmentKernel *spawn_alignment_kernel();
+void set_parameters(AlignmentParameters *parameters);
+void set_logger(AlignmentLogger *logger);
+void delete_alignment_kernel(AlignmentKernel *instance);
+#endif
+
+/* ---- (2) flat device-resident API ---- */
+typedef struct valign_hip_engine valign_hip_engine;
+
+typedef struct {
+    int32_t match, mismatch;          /* score_match, score_mismatch                      */
+    int32_t gap_read, gap_ref;        /* score_gap_read (LEFT), score_gap_ref (UP)        */
+    int32_t affine;                   /* 0: linear model above; 1: use the four below     */
+    int32_t open_read, ext_read;      /* first / further gap base in the read (LEFT)      */
+    int32_t open_ref, ext_ref;        /* first / further gap base in the ref  (UP)        */
+} valign_hip_scoring;
+
+int valign_hip_device_count(void);
+
+/* One engine = one device + fixed (read_length, ref_length, scoring), like one spawned
+ * kernel object.  force_group_lanes / force_rows_per_lane = 0 lets the engine choose. */
+int valign_hip_engine_create(int device, int read_length, int ref_length,
+                             const valign_hip_scoring *scoring, int force_group_lanes,
+                             int force_rows_per_lane, valign_hip_engine **out);
+void valign_hip_engine_destroy(valign_hip_engine *e);
+
+/* Score n pairs that are already in device memory: d_reads = n*read_length bytes and
+ * d_refs = n*ref_length bytes (raw ASCII, pair-major, NUL padded), d_scores = n int16.
+ * opt & 0xF: 0 Smith-Waterman, 1 Needleman-Wunsch variant; other values do nothing.
+ * Asynchronous on `hip_stream` (a hipStream_t; NULL = the device's default stream).    */
+int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
+                            const void *d_refs, void *d_scores, void *hip_stream);
+
+/* The plugin virtual without the C++ object: host pointers in, host scores out
+ * (gather -> pinned staging -> H2D -> kernel -> D2H, chunked and overlapped).          */
+int valign_hip_score_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
+                          const char *const *refs, short *scores, int threads);
+
+/* JSON description of what a call with this opt would launch (geometry, LDS, grid).   */
+int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap);
+
+const char *valign_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALIGN_HIP_H */

@@ -1,0 +1,138 @@
+"""GPU parity of the score path: libHIPKernel.so vs the oracle, bit-exact (integer DP).
+
+Every case goes through the C ABI: either the versalignLib plugin protocol
+(host.Plugin -> spawn_alignment_kernel -> AlignmentKernel::score_alignments) or the flat
+device-resident entry point (valign_hip_score_device)."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from versalignlib_amd import build, hipkernel, host, synth
+
+from conftest import ref_kernel
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # (R, F, n, seed)
+    (64, 128, 1000, 11),      # BASELINE config 1
+    (150, 500, 777, 12),      # headline shape, odd pair count (tail group / tail wave)
+    (12, 20, 300, 13),
+    (33, 70, 301, 14),
+    (16, 16, 64, 15),
+    (1, 1, 5, 16),
+    (100, 37, 129, 17),       # read longer than ref
+    (250, 300, 65, 18),
+    (600, 700, 17, 19),
+]
+
+
+def _data(R, F, n, seed):
+    return synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08,
+                            lowercase_frac=0.05, junk_frac=0.05)
+
+
+@pytest.mark.parametrize("R,F,n,seed", SHAPES)
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_plugin_scores_match_oracle(R, F, n, seed, gaps):
+    reads, refs = _data(R, F, n, seed)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1],
+                     num_threads=4) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.score_alignments(opt, reads, refs)
+            exp = cpu_ref.score(opt, reads, refs, sc, threads=8)
+            assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])
+
+
+@pytest.mark.parametrize("R,F,n,seed", SHAPES[:5])
+def test_plugin_scores_match_reference_kernels(R, F, n, seed):
+    """Against the reference's own compiled kernels where they travelled with the repo:
+    SSE gives full 16-bit scores, Default only the low byte (DefaultKernel.cpp:137,199)."""
+    sse, default = ref_kernel("SSE"), ref_kernel("Default")
+    if not sse or not default:
+        pytest.skip("oracle/_ref not built")
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip, host.Plugin(sse, R, F) as s, \
+            host.Plugin(default, R, F) as d:
+        for opt in (host.SW, host.NW):
+            got = hip.score_alignments(opt, reads, refs)
+            assert np.array_equal(got, s.score_alignments(opt, reads, refs))
+            assert np.array_equal(got & 0xFF, d.score_alignments(opt, reads, refs) & 0xFF)
+
+
+@pytest.mark.parametrize("R,F,n,seed", [SHAPES[0], SHAPES[1], SHAPES[3]])
+@pytest.mark.parametrize("aff", [(-5, -1, -4, -2), (-3, -3, -3, -3), (-6, -2, -6, -2)])
+def test_affine_scores(R, F, n, seed, aff):
+    """Affine extension (not in the reference): own oracle, plus open == extend == linear."""
+    reads, refs = _data(R, F, n, seed)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1],
+                score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.score_alignments(opt, reads, refs)
+            exp = cpu_ref.score(opt, reads, refs, sc, threads=8, affine=True)
+            assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])
+            if aff == (-3, -3, -3, -3):
+                lin = cpu_ref.score(opt, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3), threads=8)
+                assert np.array_equal(got, lin)
+
+
+@pytest.mark.parametrize("geom", [(8, 20), (16, 10), (16, 12), (32, 8), (64, 12)])
+def test_every_geometry_agrees(geom):
+    """The same batch through forced kernel geometries (lanes per pair group, rows per lane)."""
+    R, F, n = 150, 500, 203
+    reads, refs = _data(R, F, n, 21)
+    sc = cpu_ref.Scoring.make()
+    with host.Plugin(build.HIP_PLUGIN, R, F, hip_group_lanes=geom[0], hip_rows_per_lane=geom[1]) as hip:
+        for opt in (host.SW, host.NW):
+            assert np.array_equal(hip.score_alignments(opt, reads, refs), cpu_ref.score(opt, reads, refs, sc, threads=8))
+
+
+def test_device_resident_entry_point():
+    import torch
+    R, F, n = 150, 500, 4099
+    reads, refs = _data(R, F, n, 31)
+    eng = hipkernel.Engine(R, F)
+    d_reads = torch.from_numpy(reads).cuda()
+    d_refs = torch.from_numpy(refs).cuda()
+    for opt in (0, 1):
+        got = eng.score_device(opt, d_reads, d_refs).cpu().numpy()
+        assert np.array_equal(got, cpu_ref.score(opt, reads, refs, threads=8))
+    # unaligned views (odd byte offsets of the batch) must still be exact
+    got = eng.score_device(0, d_reads[1:], d_refs[1:]).cpu().numpy()
+    assert np.array_equal(got, cpu_ref.score(0, reads[1:], refs[1:], threads=8))
+    eng.close()
+
+
+def test_unsupported_opt_is_a_silent_noop_and_empty_batch():
+    R, F = 20, 30
+    reads, refs = _data(R, F, 10, 41)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        out = hip.score_alignments(2, reads, refs)          # opt & 0xF == 2: nothing happens
+        assert not out.any()
+        assert hip.score_alignments(0, reads[:0], refs[:0]).shape == (0,)
+
+
+def test_missing_required_key_throws_like_the_reference():
+    with pytest.raises(host.PluginError, match="Lacking parameters"):
+        host.Plugin(build.HIP_PLUGIN, 10, 10, score_match=None)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 shape at a size the oracle cannot cover in seconds: properties only.
+    (a) the batch is 64 copies of a 4096-pair block -> scores repeat with period 4096;
+    (b) the first block equals the oracle; (c) SW(read, read-as-ref prefix) sanity: identical
+    pairs score 2 * valid bases."""
+    import torch
+    R, F, blk, reps = 150, 500, 4096, 64
+    reads, refs = synth.make_pairs(blk, R, F, seed=51)
+    eng = hipkernel.Engine(R, F)
+    d_reads = torch.from_numpy(reads).cuda().repeat(reps, 1).contiguous()
+    d_refs = torch.from_numpy(refs).cuda().repeat(reps, 1).contiguous()
+    for opt in (0, 1):
+        got = eng.score_device(opt, d_reads, d_refs).cpu().numpy().reshape(reps, blk)
+        assert (got == got[0]).all()
+        assert np.array_equal(got[0], cpu_ref.score(opt, reads, refs, threads=8))
+    eng.close()

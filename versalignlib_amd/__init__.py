@@ -12,3 +12,11 @@ thin ctypes plumbing around it:
   shard ....... contiguous pair-range sharding across ranks + score all-gather
 """
 __version__ = "0.1.0"
+
+# One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64 with the
+# same sonames as /opt/rocm's.  Whichever is loaded first serves everybody, and torch cannot
+# initialise on top of the system copy, so when torch is installed let it load first.
+try:  # pragma: no cover - depends on the environment
+    import torch as _torch  # noqa: F401
+except Exception:  # torch absent: the plugin and the host harness work without it
+    _torch = None

@@ -1,0 +1,314 @@
+// hip_engine.hip.h -- host side of libHIPKernel.so: kernel selection, launches, and the
+// host-pointer path (gather -> pinned staging -> H2D -> kernel -> D2H, double buffered).
+// The closest reference precedent for the staging loop is the OpenCL backend's
+// gather/copy/launch/collect loop (src/Kernels/OpenCL/OpenCLKernel.cpp:57-108); unlike
+// it, chunks here are large (tens of MB), asynchronous and overlapped on two streams.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dp_kernels.hip.h"
+
+namespace valign {
+
+struct Scoring {
+    int match = 2, mismatch = -1, gap_read = -3, gap_ref = -3;
+    bool affine = false;
+    int open_read = -3, ext_read = -3, open_ref = -3, ext_ref = -3;
+};
+
+inline void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// One compiled (G, K) geometry with its four kernel variants.
+struct Geometry {
+    int G, K;
+    WaveLds (*lds)(int R, int F);
+    const void *kernel[2][2];      // [alg][affine]
+};
+
+template <int G, int K>
+constexpr Geometry make_geometry() {
+    return Geometry{G, K, &wave_lds<G, K>,
+                    {{(const void *)&score_kernel<G, K, kAlgSW, false>,
+                      (const void *)&score_kernel<G, K, kAlgSW, true>},
+                     {(const void *)&score_kernel<G, K, kAlgNW, false>,
+                      (const void *)&score_kernel<G, K, kAlgNW, true>}}};
+}
+
+// Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
+static const Geometry kGeometries[] = {
+    make_geometry<8, 4>(),   make_geometry<8, 8>(),   make_geometry<16, 4>(),  make_geometry<8, 12>(),
+    make_geometry<8, 16>(),  make_geometry<16, 8>(),  make_geometry<8, 20>(),  make_geometry<16, 10>(),
+    make_geometry<16, 12>(), make_geometry<16, 16>(), make_geometry<32, 8>(),  make_geometry<32, 12>(),
+    make_geometry<32, 16>(), make_geometry<64, 12>(), make_geometry<64, 16>(), make_geometry<64, 24>(),
+    make_geometry<64, 32>(),
+};
+constexpr int kNumGeometries = sizeof(kGeometries) / sizeof(kGeometries[0]);
+
+constexpr int kMaxBlockLds = 160 * 1024;       // gfx950: 160 KiB per CU, one block may take it all
+constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribute must be raised
+
+struct LaunchPlan {
+    const Geometry *geo = nullptr;
+    WaveLds lds{};
+    int waves_per_block = 4;
+    int pairs_per_wave = 0;
+};
+
+class Engine {
+public:
+    Engine(int device, int R, int F, const Scoring &sc, int force_g, int force_k)
+        : device_(device), R_(R), F_(F), sc_(sc) {
+        if (R < 0 || F < 0) throw std::runtime_error("negative sequence length");
+        if ((long long)R + F > 32767)
+            throw std::runtime_error("read_length + ref_length exceeds the ABI's 16-bit coordinates");
+        validate_scoring();
+        int count = 0;
+        hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+        if (device < 0 || device >= count)
+            throw std::runtime_error("HIP device " + std::to_string(device) + " not present (" +
+                                     std::to_string(count) + " visible): libHIPKernel.so has no CPU path");
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+        arch_ = prop.gcnArchName;
+        if (arch_.find("gfx950") == std::string::npos)
+            throw std::runtime_error("device is " + arch_ + "; this library carries gfx950 code only");
+        plan_ = choose_plan(force_g, force_k);
+        for (int s = 0; s < 2; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
+        for (int s = 0; s < 2; ++s) hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
+    }
+
+    ~Engine() {
+        (void)hipSetDevice(device_);
+        release_staging();
+        for (int s = 0; s < 2; ++s) {
+            if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
+            if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
+        }
+    }
+
+    int device() const { return device_; }
+    const LaunchPlan &plan() const { return plan_; }
+    hipStream_t own_stream() const { return streams_[0]; }
+
+    // Device-resident batch, asynchronous on `stream`.
+    void score_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs,
+                      int16_t *d_scores, hipStream_t stream) {
+        const int alg = opt & 0xF;
+        if (alg > 1 || n <= 0) return;          // reference: unsupported mode is a silent no-op
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        ScoreArgs a;
+        a.reads = d_reads;
+        a.refs = d_refs;
+        a.scores = d_scores;
+        a.n = n;
+        a.R = R_;
+        a.F = F_;
+        a.prof_area = plan_.lds.prof_area;
+        a.refc_stride = plan_.lds.refc_stride;
+        a.wave_lds = plan_.lds.total;
+        a.match = (short)sc_.match;
+        a.mismatch = (short)sc_.mismatch;
+        a.gap_read = (short)sc_.gap_read;
+        a.gap_ref = (short)sc_.gap_ref;
+        a.open_read = (short)sc_.open_read;
+        a.ext_read = (short)sc_.ext_read;
+        a.open_ref = (short)sc_.open_ref;
+        a.ext_ref = (short)sc_.ext_ref;
+        const void *fn = plan_.geo->kernel[alg][sc_.affine ? 1 : 0];
+        const int block_lds = plan_.lds.total * plan_.waves_per_block;
+        if (block_lds > kDefaultBlockLds)
+            hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        const long long pairs_per_block = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
+        const long long blocks = (n + pairs_per_block - 1) / pairs_per_block;
+        if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
+        void *kargs[] = {&a};
+        hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), kargs,
+                                  (size_t)block_lds, stream),
+                  "hipLaunchKernel(score_kernel)");
+    }
+
+    // Host pointers in, host scores out.  Chunked: while chunk c runs on the device the
+    // host threads gather chunk c+1 into the other pinned slot.
+    void score_host(int opt, int n, const char *const *reads, const char *const *refs, short *scores,
+                    int threads) {
+        const int alg = opt & 0xF;
+        if (alg > 1 || n <= 0) return;
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        const size_t per_pair = (size_t)R_ + F_;
+        long long chunk = per_pair ? (long long)((48u << 20) / per_pair) : n;
+        chunk = std::max<long long>(chunk, 1024);
+        chunk = std::min<long long>(chunk, n);
+        ensure_staging(chunk);
+        if (threads < 1) threads = 1;
+        threads = std::min(threads, 64);
+        int slot = 0;
+        for (long long begin = 0; begin < n; begin += chunk, slot ^= 1) {
+            const long long cnt = std::min<long long>(chunk, n - begin);
+            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
+            if (slot_pending_[slot] > 0) {         // drain the result of the chunk that used this slot
+                memcpy(scores + slot_begin_[slot], h_scores_[slot], sizeof(short) * (size_t)slot_pending_[slot]);
+                slot_pending_[slot] = 0;
+            }
+            gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
+            hipStream_t st = streams_[slot];
+            hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
+            hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
+            score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+            hip_check(hipMemcpyAsync(h_scores_[slot], d_scores_[slot], sizeof(short) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H scores");
+            hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
+            slot_begin_[slot] = begin;
+            slot_pending_[slot] = cnt;
+        }
+        for (int s = 0; s < 2; ++s) {
+            hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
+            if (slot_pending_[s] > 0) {
+                memcpy(scores + slot_begin_[s], h_scores_[s], sizeof(short) * (size_t)slot_pending_[s]);
+                slot_pending_[s] = 0;
+            }
+        }
+    }
+
+    std::string describe(int opt, long long n) const {
+        const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
+        char buf[512];
+        snprintf(buf, sizeof buf,
+                 "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
+                 "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
+                 "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld}",
+                 arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
+                 plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
+                 plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0);
+        return buf;
+    }
+
+private:
+    void validate_scoring() {
+        auto fits = [](int v) { return v >= -32768 && v <= 32767; };
+        if (!fits(sc_.match) || !fits(sc_.mismatch) || !fits(sc_.gap_read) || !fits(sc_.gap_ref) ||
+            !fits(sc_.open_read) || !fits(sc_.ext_read) || !fits(sc_.open_ref) || !fits(sc_.ext_ref))
+            throw std::runtime_error("scoring parameter outside int16");
+        // The row padding and the unsigned floor-at-zero arithmetic need non-positive gap scores.
+        const bool gaps_ok = sc_.affine ? (sc_.open_read <= 0 && sc_.ext_read <= 0 && sc_.open_ref <= 0 && sc_.ext_ref <= 0)
+                                        : (sc_.gap_read <= 0 && sc_.gap_ref <= 0);
+        if (!gaps_ok) throw std::runtime_error("positive gap scores are not supported by the HIP kernels");
+        // int16 DP: the reference wraps silently; refuse shapes where it could.
+        const long long lo = (long long)(R_ + F_ + 2) * std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref,
+                                                                  sc_.ext_read, sc_.ext_ref, sc_.mismatch, 0});
+        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        if (hi > 32000 || lo < -16000)
+            throw std::runtime_error("shape x scoring can leave the int16 range of the DP cells");
+    }
+
+    LaunchPlan choose_plan(int force_g, int force_k) const {
+        LaunchPlan best;
+        double best_cost = 0;
+        for (int i = 0; i < kNumGeometries; ++i) {
+            const Geometry &g = kGeometries[i];
+            if (g.G * g.K < R_) continue;
+            if (force_g && (g.G != force_g || (force_k && g.K != force_k))) continue;
+            if (!force_g && force_k && g.K != force_k) continue;
+            LaunchPlan p;
+            p.geo = &g;
+            p.lds = g.lds(R_, F_);
+            p.pairs_per_wave = 2 * (kWave / g.G);
+            p.waves_per_block = 4;
+            while (p.waves_per_block > 1 && p.lds.total * p.waves_per_block > kDefaultBlockLds) p.waves_per_block >>= 1;
+            if (p.lds.total * p.waves_per_block > kMaxBlockLds) continue;
+            // lane-steps per pair, weighted by instructions per step (per-row work + fixed part)
+            const double per_step = g.K * (sc_.affine ? 11.0 : 7.0) + 14.0;
+            double cost = (double)(F_ + g.G - 1) * per_step * g.G / 2.0;
+            const int waves_per_cu = std::min(16, kMaxBlockLds / std::max(1, p.lds.total));
+            if (waves_per_cu < 8) cost *= 1.0 + 0.15 * (8 - waves_per_cu);      // too few waves to fill the SIMDs
+            if (!best.geo || cost < best_cost) {
+                best = p;
+                best_cost = cost;
+            }
+        }
+        if (!best.geo)
+            throw std::runtime_error("no kernel geometry fits read_length=" + std::to_string(R_) + ", ref_length=" +
+                                     std::to_string(F_) + " (rows <= 2048 and LDS <= 160 KiB per block are supported)");
+        return best;
+    }
+
+    void release_staging() {
+        for (int s = 0; s < 2; ++s) {
+            if (h_reads_[s]) (void)hipHostFree(h_reads_[s]);
+            if (h_refs_[s]) (void)hipHostFree(h_refs_[s]);
+            if (h_scores_[s]) (void)hipHostFree(h_scores_[s]);
+            if (d_reads_[s]) (void)hipFree(d_reads_[s]);
+            if (d_refs_[s]) (void)hipFree(d_refs_[s]);
+            if (d_scores_[s]) (void)hipFree(d_scores_[s]);
+            h_reads_[s] = h_refs_[s] = nullptr;
+            h_scores_[s] = nullptr;
+            d_reads_[s] = d_refs_[s] = nullptr;
+            d_scores_[s] = nullptr;
+        }
+        staged_pairs_ = 0;
+    }
+
+    void ensure_staging(long long pairs) {
+        if (pairs <= staged_pairs_) return;
+        release_staging();
+        for (int s = 0; s < 2; ++s) {
+            hip_check(hipHostMalloc((void **)&h_reads_[s], std::max<size_t>((size_t)pairs * R_, 16), hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc((void **)&h_refs_[s], std::max<size_t>((size_t)pairs * F_, 16), hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc((void **)&h_scores_[s], sizeof(short) * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipMalloc((void **)&d_reads_[s], std::max<size_t>((size_t)pairs * R_, 16)), "hipMalloc");
+            hip_check(hipMalloc((void **)&d_refs_[s], std::max<size_t>((size_t)pairs * F_, 16)), "hipMalloc");
+            hip_check(hipMalloc((void **)&d_scores_[s], sizeof(short) * (size_t)pairs), "hipMalloc");
+        }
+        staged_pairs_ = pairs;
+    }
+
+    void gather(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads,
+                uint8_t *dst_refs, int threads) const {
+        const int R = R_, F = F_;
+        auto work = [=](long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                memcpy(dst_reads + (size_t)i * R, reads[i], (size_t)R);
+                memcpy(dst_refs + (size_t)i * F, refs[i], (size_t)F);
+            }
+        };
+        if (threads <= 1 || cnt < 4096) {
+            work(0, cnt);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const long long per = (cnt + threads - 1) / threads;
+        for (int t = 0; t < threads; ++t) {
+            const long long lo = t * per, hi = std::min(cnt, lo + per);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto &th : pool) th.join();
+    }
+
+    int device_, R_, F_;
+    Scoring sc_;
+    std::string arch_;
+    LaunchPlan plan_;
+    hipStream_t streams_[2] = {nullptr, nullptr};
+    hipEvent_t slot_done_[2] = {nullptr, nullptr};
+    long long slot_begin_[2] = {0, 0}, slot_pending_[2] = {0, 0};
+    long long staged_pairs_ = 0;
+    uint8_t *h_reads_[2] = {nullptr, nullptr}, *h_refs_[2] = {nullptr, nullptr};
+    short *h_scores_[2] = {nullptr, nullptr};
+    uint8_t *d_reads_[2] = {nullptr, nullptr}, *d_refs_[2] = {nullptr, nullptr};
+    int16_t *d_scores_[2] = {nullptr, nullptr};
+};
+
+}  // namespace valign

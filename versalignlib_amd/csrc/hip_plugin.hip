@@ -1,0 +1,208 @@
+// hip_plugin.hip -- libHIPKernel.so: the versalignLib plugin boundary over the HIP engine.
+//
+// Exports the four C symbols every versalignLib backend exports
+// (src/Kernels/default/DefaultKernel_dllexport.cpp:18-42) plus the flat C API of
+// include/valign_hip.h.  There is deliberately no CPU path: without a gfx950 device
+// spawn_alignment_kernel() fails loudly.
+#include "valign_hip.h"
+#include "versalign_plugin_abi.h"
+
+#include <exception>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "hip_engine.hip.h"
+
+#define VALIGN_EXPORT __attribute__((visibility("default")))
+
+// Plugin-private globals the ABI headers declare (AlignmentParameters.h:21, AlignmentLogger.h:21).
+VALIGN_EXPORT AlignmentParameters *_parameters = 0;
+VALIGN_EXPORT AlignmentLogger *_logger = 0;
+
+namespace {
+
+const char *const kModule = "HIP";
+thread_local std::string g_last_error;
+
+int opt_param(const char *key, int fallback) {
+    return Parameters.has_key(key) ? Parameters.param_int(key) : fallback;
+}
+
+void log_line(int level, const std::string &msg) {
+    if (_logger) Logger.log(level, kModule, msg.c_str());
+}
+
+// The kernel object handed to the host.  Reads the same six required keys as every
+// reference backend at construction (DefaultKernel.h:70-81) and num_threads per call
+// (DefaultKernel.cpp:45); the latter sizes the host gather pool here.
+class HIPKernel : public AlignmentKernel {
+public:
+    HIPKernel() {
+        if (!_parameters) throw "Cannot instantiate Kernel. Lacking parameters";
+        static const char *const required[] = {"score_match", "score_mismatch", "score_gap_read",
+                                               "score_gap_ref", "read_length", "ref_length"};
+        for (const char *key : required)
+            if (!Parameters.has_key(key)) throw "Cannot instantiate Kernel. Lacking parameters";
+        valign::Scoring sc;
+        sc.match = Parameters.param_int("score_match");
+        sc.mismatch = Parameters.param_int("score_mismatch");
+        sc.gap_read = Parameters.param_int("score_gap_read");
+        sc.gap_ref = Parameters.param_int("score_gap_ref");
+        const int R = Parameters.param_int("read_length");
+        const int F = Parameters.param_int("ref_length");
+        const bool any_affine = Parameters.has_key("score_gap_open_read") || Parameters.has_key("score_gap_extend_read") ||
+                                Parameters.has_key("score_gap_open_ref") || Parameters.has_key("score_gap_extend_ref");
+        if (any_affine) {
+            sc.affine = true;
+            sc.open_read = opt_param("score_gap_open_read", sc.gap_read);
+            sc.ext_read = opt_param("score_gap_extend_read", sc.gap_read);
+            sc.open_ref = opt_param("score_gap_open_ref", sc.gap_ref);
+            sc.ext_ref = opt_param("score_gap_extend_ref", sc.gap_ref);
+        } else {
+            sc.open_read = sc.ext_read = sc.gap_read;
+            sc.open_ref = sc.ext_ref = sc.gap_ref;
+        }
+        try {
+            engine_.reset(new valign::Engine(opt_param("hip_device", 0), R, F, sc, opt_param("hip_group_lanes", 0),
+                                             opt_param("hip_rows_per_lane", 0)));
+        } catch (const std::exception &e) {
+            what_ = std::string("Cannot instantiate Kernel. ") + e.what();
+            log_line(3, what_);
+            static thread_local std::string thrown;
+            thrown = what_;
+            throw thrown.c_str();          // hosts catch `const char *` (reference convention)
+        }
+#ifndef NDEBUG
+        log_line(0, "Successfully instantiated HIP Kernel.");
+#endif
+    }
+
+    ~HIPKernel() override {}
+
+    void score_alignments(int const &opt, int const &aln_number, char const *const *const reads,
+                          char const *const *const refs, short *const scores) override {
+        if ((opt & 0xF) > 1) return;       // unsupported mode: silent no-op, like the reference
+        const int threads = Parameters.has_key("num_threads") ? Parameters.param_int("num_threads") : 1;
+        log_line(0, "Running HIPKernel score with " + std::to_string(threads) + " host threads on " +
+                        engine_->describe(opt, aln_number));
+        try {
+            engine_->score_host(opt, aln_number, reads, refs, scores, threads);
+        } catch (const std::exception &e) {
+            log_line(3, e.what());
+            throw;
+        }
+    }
+
+    void compute_alignments(int const &opt, int const &aln_number, char const *const *const reads,
+                            char const *const *const refs, Alignment *const alignments) override {
+        if ((opt & 0xF) > 1) return;
+        (void)aln_number; (void)reads; (void)refs; (void)alignments;
+        log_line(3, "compute_alignments is not implemented in the HIP backend yet");
+        throw std::runtime_error("HIPKernel::compute_alignments: not implemented yet");
+    }
+
+private:
+    std::unique_ptr<valign::Engine> engine_;
+    std::string what_;
+};
+
+template <typename Fn>
+int flat_guard(Fn &&fn) {
+    try {
+        fn();
+        return 0;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+    } catch (const char *msg) {
+        g_last_error = msg ? msg : "error";
+    } catch (...) {
+        g_last_error = "unknown error";
+    }
+    return 1;
+}
+
+}  // namespace
+
+struct valign_hip_engine {
+    std::unique_ptr<valign::Engine> impl;
+};
+
+extern "C" {
+
+VALIGN_EXPORT AlignmentKernel *spawn_alignment_kernel() {
+    AlignmentKernel *kernel = new HIPKernel();
+    return kernel;
+}
+
+VALIGN_EXPORT void set_parameters(AlignmentParameters *parameters) { _parameters = parameters; }
+
+VALIGN_EXPORT void set_logger(AlignmentLogger *logger) { _logger = logger; }
+
+VALIGN_EXPORT void delete_alignment_kernel(AlignmentKernel *instance) {
+    if (instance != 0) delete instance;
+}
+
+VALIGN_EXPORT const char *valign_hip_last_error(void) { return g_last_error.c_str(); }
+
+VALIGN_EXPORT int valign_hip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+VALIGN_EXPORT int valign_hip_engine_create(int device, int read_length, int ref_length,
+                                           const valign_hip_scoring *s, int force_group_lanes,
+                                           int force_rows_per_lane, valign_hip_engine **out) {
+    if (!s || !out) {
+        g_last_error = "null argument";
+        return 1;
+    }
+    return flat_guard([&] {
+        valign::Scoring sc;
+        sc.match = s->match;
+        sc.mismatch = s->mismatch;
+        sc.gap_read = s->gap_read;
+        sc.gap_ref = s->gap_ref;
+        sc.affine = s->affine != 0;
+        sc.open_read = sc.affine ? s->open_read : s->gap_read;
+        sc.ext_read = sc.affine ? s->ext_read : s->gap_read;
+        sc.open_ref = sc.affine ? s->open_ref : s->gap_ref;
+        sc.ext_ref = sc.affine ? s->ext_ref : s->gap_ref;
+        std::unique_ptr<valign_hip_engine> e(new valign_hip_engine());
+        e->impl.reset(new valign::Engine(device, read_length, ref_length, sc, force_group_lanes, force_rows_per_lane));
+        *out = e.release();
+    });
+}
+
+VALIGN_EXPORT void valign_hip_engine_destroy(valign_hip_engine *e) { delete e; }
+
+VALIGN_EXPORT int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
+                                          const void *d_refs, void *d_scores, void *hip_stream) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] {
+        e->impl->score_device(opt, n, (const uint8_t *)d_reads, (const uint8_t *)d_refs, (int16_t *)d_scores,
+                              (hipStream_t)hip_stream);
+    });
+}
+
+VALIGN_EXPORT int valign_hip_score_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
+                                        const char *const *refs, short *scores, int threads) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->score_host(opt, n, reads, refs, scores, threads); });
+}
+
+VALIGN_EXPORT int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap) {
+    if (!e || !buf || cap <= 0) return 1;
+    const std::string s = e->impl->describe(opt, n);
+    snprintf(buf, (size_t)cap, "%s", s.c_str());
+    return 0;
+}
+
+}  // extern "C"

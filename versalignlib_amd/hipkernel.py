@@ -1,0 +1,130 @@
+"""ctypes plumbing over lib/libHIPKernel.so's flat C API (include/valign_hip.h).
+
+`Engine` is the device-resident twin of a spawned kernel object: fixed
+(read_length, ref_length, scoring), batches passed as device pointers.  torch is used
+only to own device memory and streams.  There is no CPU fallback: constructing an
+Engine without a gfx950 device raises.
+"""
+import ctypes
+import json
+import os
+
+from . import build as _build
+
+SW = 0
+NW = 1
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class Scoring(ctypes.Structure):
+    """Mirror of valign_hip_scoring."""
+
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "match", "mismatch", "gap_read", "gap_ref", "affine",
+        "open_read", "ext_read", "open_ref", "ext_ref")]
+
+    @classmethod
+    def make(cls, match=2, mismatch=-1, gap_read=-3, gap_ref=-3,
+             open_read=None, ext_read=None, open_ref=None, ext_ref=None):
+        affine = any(v is not None for v in (open_read, ext_read, open_ref, ext_ref))
+        return cls(match, mismatch, gap_read, gap_ref, 1 if affine else 0,
+                   gap_read if open_read is None else open_read,
+                   gap_read if ext_read is None else ext_read,
+                   gap_ref if open_ref is None else open_ref,
+                   gap_ref if ext_ref is None else ext_ref)
+
+
+def plugin_path():
+    return _build.HIP_PLUGIN
+
+
+def lib():
+    """Load libHIPKernel.so; raises if it has not been built (never falls back)."""
+    global _lib
+    if _lib is None:
+        path = plugin_path()
+        if not os.path.exists(path):
+            raise HipKernelError(
+                "libHIPKernel.so is missing (%s): run `python -m versalignlib_amd.build`" % path)
+        L = ctypes.CDLL(path)
+        vp = ctypes.c_void_p
+        L.valign_hip_device_count.restype = ctypes.c_int
+        L.valign_hip_engine_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(Scoring), ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(vp)]
+        L.valign_hip_engine_destroy.restype = None
+        L.valign_hip_engine_destroy.argtypes = [vp]
+        L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
+        L.valign_hip_score_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int]
+        L.valign_hip_describe.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_char_p,
+                                          ctypes.c_int]
+        L.valign_hip_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = (
+    "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
+    "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
+    "valign_hip_score_device", "valign_hip_score_host", "valign_hip_describe",
+    "valign_hip_last_error",
+)
+
+
+def _err():
+    return lib().valign_hip_last_error().decode(errors="replace")
+
+
+class Engine:
+    def __init__(self, read_length, ref_length, scoring=None, device=0, group_lanes=0,
+                 rows_per_lane=0):
+        self.read_length = int(read_length)
+        self.ref_length = int(ref_length)
+        self.scoring = scoring or Scoring.make()
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        rc = lib().valign_hip_engine_create(self.device, self.read_length, self.ref_length,
+                                            ctypes.byref(self.scoring), int(group_lanes),
+                                            int(rows_per_lane), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise HipKernelError(_err())
+
+    def score_device(self, opt, reads, refs, scores=None, stream=None):
+        """reads/refs: torch uint8 CUDA tensors [n, R] / [n, F]; -> int16 CUDA tensor [n].
+
+        Asynchronous on torch's current stream (or `stream`)."""
+        import torch
+        n = reads.shape[0]
+        assert reads.is_cuda and refs.is_cuda and reads.dtype == torch.uint8 and refs.dtype == torch.uint8
+        assert reads.is_contiguous() and refs.is_contiguous()
+        assert tuple(reads.shape) == (n, self.read_length) and tuple(refs.shape) == (n, self.ref_length)
+        if scores is None:
+            scores = torch.empty(n, dtype=torch.int16, device=reads.device)
+        st = stream if stream is not None else torch.cuda.current_stream(reads.device)
+        rc = lib().valign_hip_score_device(self._h, int(opt), n, reads.data_ptr(), refs.data_ptr(),
+                                           scores.data_ptr(), st.cuda_stream)
+        if rc != 0:
+            raise HipKernelError(_err())
+        return scores
+
+    def describe(self, opt=0, n=0):
+        buf = ctypes.create_string_buffer(1024)
+        lib().valign_hip_describe(self._h, int(opt), int(n), buf, len(buf))
+        return json.loads(buf.value.decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().valign_hip_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
