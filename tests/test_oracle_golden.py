@@ -1,0 +1,82 @@
+"""The oracle pinned against outputs of the reference's own compiled kernels.
+
+tests/golden/*.npz were produced by tests/golden/make_golden.py from
+libSSEKernel.so (full scores) and libDefaultKernel.so (score low byte, alignments) built
+from the reference sources; the known-answer cases are SURVEY.md Appendix C."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+
+from golden_util import golden_files, load, rows_text
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_reproduces_reference_outputs(path):
+    g = load(path)
+    m, x, gr, gf = (int(v) for v in g["scoring"])
+    sc = cpu_ref.Scoring.make(m, x, gr, gf)
+    for opt, tag in ((0, "sw"), (1, "nw")):
+        s = cpu_ref.score(opt, g["reads"], g["refs"], sc)
+        assert np.array_equal(s, g["score_" + tag])                       # SSE: full int16
+        assert np.array_equal((s & 0xFF).astype(np.uint8), g["lowbyte_" + tag])   # Default: low byte
+        rows, idx = cpu_ref.align(opt, g["reads"], g["refs"], sc)
+        assert np.array_equal(idx, g["idx_" + tag])
+        assert np.array_equal(rows, g["rows_" + tag])
+
+
+KAT_EXPECT = [  # SW score, SW rows, SW start, NW score, NW rows, NW start
+    (8, (b"ACGT", b"ACGT"), 7, 8, (b"ACGT", b"ACGT"), 7),
+    (8, (b"ACGT", b"ACGT"), 11, 8, (b"ACGT", b"ACGT"), 11),
+    (6, (b"ACNT", b"ACGT"), 7, 6, (b"ACNT", b"ACGT"), 7),
+    (0, (b"", b""), 11, 0, (b"AAAA", b"CCCC"), 7),
+    (10, (b"TGACC", b"TGACC"), 12, 10, (b"ACGTTTGACC", b"ACG--TGACC"), 7),
+    (4, (b"AT", b"AT"), 11, 3, (b"GATTACA", b"GCATGCT"), 6),
+]
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_known_answers(k):
+    g = load([p for p in golden_files() if p.endswith("kat%d.npz" % (k + 1))][0])
+    sw_score, sw_rows, sw_start, nw_score, nw_rows, nw_start = KAT_EXPECT[k]
+    assert int(cpu_ref.score(0, g["reads"], g["refs"])[0]) == sw_score
+    assert int(cpu_ref.score(1, g["reads"], g["refs"])[0]) == nw_score
+    rows, idx = cpu_ref.align(0, g["reads"], g["refs"])
+    assert rows_text(rows[0], idx[0]) == sw_rows and idx[0, 0] == sw_start == idx[0, 2]
+    rows, idx = cpu_ref.align(1, g["reads"], g["refs"])
+    assert rows_text(rows[0], idx[0]) == nw_rows and idx[0, 0] == nw_start
+    R, F = g["reads"].shape[1], g["refs"].shape[1]
+    assert idx[0, 1] == R + F - 1 == idx[0, 3]
+
+
+def test_affine_degenerates_to_linear():
+    """Affine extension is unpinned by the reference; open == extend must equal linear."""
+    from versalignlib_amd import synth
+    for R, F, seed in ((20, 30, 1), (64, 128, 2), (150, 500, 3)):
+        reads, refs = synth.make_pairs(64, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.1, short_frac=0.1)
+        for gr, gf in ((-3, -3), (-2, -5)):
+            lin = cpu_ref.Scoring.make(2, -1, gr, gf)
+            aff = cpu_ref.Scoring.make(2, -1, gr, gf, gr, gr, gf, gf)
+            for opt in (0, 1):
+                assert np.array_equal(cpu_ref.score(opt, reads, refs, lin),
+                                      cpu_ref.score(opt, reads, refs, aff, affine=True))
+
+
+def test_affine_prefers_one_long_gap():
+    # read = ref with a 4-base deletion: affine (open -5, extend -1) keeps one gap, score 2*16-5-3
+    ref = b"ACGTACGTTTGGCCAAGTCA"
+    read = ref[:8] + ref[12:]
+    reads = np.frombuffer(read, np.uint8)[None, :].copy()
+    refs = np.frombuffer(ref, np.uint8)[None, :].copy()
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1)
+    assert int(cpu_ref.score(0, reads, refs, sc, affine=True)[0]) == 2 * 16 - 5 - 3
+    assert int(cpu_ref.score(0, reads, refs, cpu_ref.Scoring.make())[0]) < 2 * 16 - 5 - 3
+
+
+def test_oracle_threads_and_noop():
+    from versalignlib_amd import synth
+    reads, refs = synth.make_pairs(50, 30, 40, seed=9)
+    a = cpu_ref.score(0, reads, refs, threads=1)
+    b = cpu_ref.score(0, reads, refs, threads=4)
+    assert np.array_equal(a, b)
+    assert not cpu_ref.score(2, reads, refs).any()       # opt & 0xF == 2: silent no-op
