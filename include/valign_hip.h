@@ -77,6 +77,15 @@ void valign_hip_engine_destroy(valign_hip_engine *e);
 int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
                             const void *d_refs, void *d_scores, void *hip_stream);
 
+/* Align n device-resident pairs (reference linear gap model): d_rows = n * 2 * (R+F) bytes,
+ * per pair the read row then the ref row -- right-justified gapped strings in
+ * [start, R+F-2], zeros before start, NUL at R+F-1 -- and d_idx = n * 4 int16
+ * (readStart, readEnd, refStart, refEnd), i.e. the contents of the ABI's `Alignment`
+ * (include/AlignmentKernel.h:12-18) flattened.  Tie-breaks follow the Default kernel.
+ * Asynchronous on `hip_stream`; uses an internal pointer scratch (<= 3 GiB).            */
+int valign_hip_align_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
+                            const void *d_refs, void *d_rows, void *d_idx, void *hip_stream);
+
 /* The plugin virtual without the C++ object: host pointers in, host scores out
  * (gather -> pinned staging -> H2D -> kernel -> D2H, chunked and overlapped).          */
 int valign_hip_score_host(valign_hip_engine *e, int opt, int n, const char *const *reads,

@@ -1,0 +1,125 @@
+"""GPU parity of compute_alignments: gapped rows + coordinates, bit-exact against the oracle
+(which is pinned to the reference Default kernel's tie-breaks) and against the committed
+Default-kernel fixtures.  All calls go through the plugin ABI or the flat C entry point."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from versalignlib_amd import build, hipkernel, host, synth
+
+from conftest import ref_kernel
+from golden_util import golden_files, load
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (64, 128, 500, 11),
+    (150, 500, 333, 12),
+    (12, 20, 300, 13),
+    (33, 70, 301, 14),
+    (16, 16, 65, 15),
+    (1, 1, 5, 16),
+    (100, 37, 129, 17),
+    (250, 300, 33, 18),
+]
+
+
+def _data(R, F, n, seed):
+    return synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.06, short_frac=0.1,
+                            lowercase_frac=0.05, junk_frac=0.05)
+
+
+def _assert_same(got, exp, what):
+    rows, idx = got
+    erows, eidx = exp
+    bad = np.nonzero((idx != eidx).any(axis=1))[0]
+    assert bad.size == 0, (what, "idx", bad[:5], idx[bad[:3]], eidx[bad[:3]])
+    bad = np.nonzero((rows != erows).any(axis=(1, 2)))[0]
+    assert bad.size == 0, (what, "rows", bad[:5])
+
+
+@pytest.mark.parametrize("R,F,n,seed", SHAPES)
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_plugin_alignments_match_oracle(R, F, n, seed, gaps):
+    reads, refs = _data(R, F, n, seed)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1],
+                     num_threads=4) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            exp = cpu_ref.align(opt, reads, refs, sc, threads=8)
+            _assert_same(got, exp, ("opt", opt))
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_plugin_alignments_match_default_kernel_fixtures(path):
+    g = load(path)
+    R, F = g["reads"].shape[1], g["refs"].shape[1]
+    m, x, gr, gf = (int(v) for v in g["scoring"])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=m, score_mismatch=x, score_gap_read=gr,
+                     score_gap_ref=gf) as hip:
+        for opt, tag in ((0, "sw"), (1, "nw")):
+            got = hip.compute_alignments(opt, g["reads"], g["refs"], normalise=False)
+            _assert_same(got, (g["rows_" + tag], g["idx_" + tag]), (path, tag))
+            assert np.array_equal(hip.score_alignments(opt, g["reads"], g["refs"]), g["score_" + tag])
+
+
+def test_plugin_alignments_match_reference_default_live():
+    default = ref_kernel("Default")
+    if not default:
+        pytest.skip("oracle/_ref not built")
+    R, F, n = 150, 500, 200
+    reads, refs = synth.make_pairs(n, R, F, seed=91, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip, host.Plugin(default, R, F) as d:
+        for opt in (0, 1):
+            _assert_same(hip.compute_alignments(opt, reads, refs), d.compute_alignments(opt, reads, refs), opt)
+
+
+@pytest.mark.parametrize("geom", [(8, 20), (16, 10), (32, 8), (64, 12)])
+def test_alignment_geometries(geom):
+    R, F, n = 150, 500, 131
+    reads, refs = _data(R, F, n, 23)
+    with host.Plugin(build.HIP_PLUGIN, R, F, hip_group_lanes=geom[0], hip_rows_per_lane=geom[1]) as hip:
+        for opt in (0, 1):
+            _assert_same(hip.compute_alignments(opt, reads, refs, normalise=False),
+                         cpu_ref.align(opt, reads, refs, threads=8), (geom, opt))
+
+
+def test_align_device_entry_point_and_roundtrip_property():
+    """Device entry point at a larger batch; plus a size-independent property: stripping the
+    gaps from the two rows gives back substrings of the read / ref ending at the reported cell,
+    and re-scoring the rows column by column reproduces the SW score."""
+    import torch
+    R, F, n = 150, 500, 20000
+    reads, refs = synth.make_pairs(n, R, F, seed=61, indel_rate=0.01)
+    eng = hipkernel.Engine(R, F)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    rows, idx = eng.align_device(0, d_reads, d_refs)
+    scores = eng.score_device(0, d_reads, d_refs).cpu().numpy()
+    rows, idx = rows.cpu().numpy(), idx.cpu().numpy()
+    erows, eidx = cpu_ref.align(0, reads[:3000], refs[:3000], threads=8)
+    _assert_same((rows[:3000], idx[:3000]), (erows, eidx), "device entry")
+    cls = np.zeros(256, np.int64)
+    for ch, c in zip(b"ATCG", (1, 2, 3, 4)):
+        cls[ch] = c
+        cls[ch | 0x20] = c
+    AL = R + F
+    assert (idx[:, 1] == AL - 1).all() and (idx[:, 3] == AL - 1).all() and (idx[:, 0] == idx[:, 2]).all()
+    for i in range(0, n, 97):
+        s = idx[i, 0]
+        a, b = rows[i, 0, s:AL - 1], rows[i, 1, s:AL - 1]
+        ca, cb = cls[a], cls[b]
+        col = np.where((a == ord("-")), -3, np.where(b == ord("-"), -3,
+                       np.where((ca > 0) & (cb > 0), np.where(ca == cb, 2, -1), 0)))
+        assert col.sum() == scores[i]
+        assert bytes(a[a != ord("-")]) in bytes(reads[i]) and bytes(b[b != ord("-")]) in bytes(refs[i])
+    eng.close()
+
+
+def test_affine_alignments_are_refused_loudly():
+    R, F = 20, 30
+    reads, refs = _data(R, F, 4, 5)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_open_read=-5, score_gap_extend_read=-1,
+                     score_gap_open_ref=-5, score_gap_extend_ref=-1) as hip:
+        with pytest.raises(host.PluginError, match="linear gap model"):
+            hip.compute_alignments(0, reads, refs)

@@ -1,0 +1,18 @@
+"""Summarise rocprofv3 --pmc CSVs (counter_collection) per kernel: mean per dispatch."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"]
+        if "valign" not in name:
+            continue
+        short = name.split("(")[0].replace("void valign::", "")
+        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}
+print(json.dumps(out, indent=1))

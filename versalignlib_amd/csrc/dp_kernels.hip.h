@@ -123,43 +123,58 @@ __device__ __forceinline__ void stage_span(unsigned char *dst, const uint8_t *sr
 
 extern __shared__ __align__(16) unsigned char valign_smem[];
 
-template <int G, int K, int ALG, bool AFFINE>
-__global__ void __launch_bounds__(256)
-score_kernel(const ScoreArgs args) {
+// Per-wave LDS tables shared by the score and the alignment-fill kernels.
+struct WaveTables {
+    unsigned char *prof;    // [5 classes][pairs][lane rows] int16 substitution scores
+    unsigned char *refc;    // [groups][2 * F] class codes, pair A / pair B interleaved
+    int *first_bad;         // [pairs][2]: first read / ref position whose class is 0 (else R / F)
+    long long pair0;        // first pair of this wave
+    int last;               // index of the last existing pair of the wave (tail waves are short)
+};
+
+// Stage the wave's raw reads/refs with coalesced 16-byte loads, then build the class-code
+// arrays and the query profile.  Returns false for a wave past the end of the batch
+// (it still takes part in the block barriers).
+template <int G, int K, bool FIND_BAD>
+__device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
+                                           int prof_area, int refc_stride, int wave_lds, short match,
+                                           short mismatch, WaveTables &w) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const int grp = lane / G;
-    const int l = lane % G;
-    const int R = args.R, F = args.F;
     const int pad_rows = geo::kRows - R;
 
-    unsigned char *lds = valign_smem + (size_t)wave * args.wave_lds;
-    unsigned char *prof = lds;                                   // 5 classes x pairs x rows
-    unsigned char *refc = lds + args.prof_area;                  // groups x (A,B interleaved)
-    unsigned char *rstage = refc + geo::kGroups * args.refc_stride;   // raw reads of the wave
+    unsigned char *lds = valign_smem + (size_t)wave * wave_lds;
+    unsigned char *prof = lds;
+    unsigned char *refc = lds + prof_area;
+    unsigned char *rstage = refc + geo::kGroups * refc_stride;   // raw reads of the wave
+    int *first_bad = reinterpret_cast<int *>(lds + wave_lds - geo::kPairs * 8);
 
     const int waves = blockDim.x / kWave;
     const long long pair0 = ((long long)blockIdx.x * waves + wave) * geo::kPairs;
-    const bool live = pair0 < args.n;
+    const bool live = pair0 < n;
     long long pair_end = pair0 + geo::kPairs;
-    if (pair_end > args.n) pair_end = args.n;
+    if (pair_end > n) pair_end = n;
+    const int last = (int)(pair_end - pair0) - 1;
 
     // ---- stage raw bytes: refs into the (not yet built) profile area, reads beside ----
     long long ref_lo = 0, read_lo = 0;
     if (live) {
         ref_lo = pair0 * F;
         read_lo = pair0 * R;
-        stage_span(prof, args.refs, ref_lo, pair_end * F, lane);
-        stage_span(rstage, args.reads, read_lo, pair_end * R, lane);
+        stage_span(prof, refs, ref_lo, pair_end * F, lane);
+        stage_span(rstage, reads, read_lo, pair_end * R, lane);
+        if (FIND_BAD && lane < geo::kPairs) {
+            first_bad[2 * lane] = R;
+            first_bad[2 * lane + 1] = F;
+        }
     }
     __syncthreads();
-    const int ref_skew = (int)((unsigned long long)(args.refs + ref_lo) & 15ull);
-    const int read_skew = (int)((unsigned long long)(args.reads + read_lo) & 15ull);
+    const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
+    const int read_skew = (int)((unsigned long long)(reads + read_lo) & 15ull);
 
     // ---- reference bases -> profile class (0..3 = A,T,C,G; 4 = scores nothing) ----
     if (live) {
-        const int last = (int)(pair_end - pair0) - 1;
         for (int idx = lane; idx < geo::kGroups * F; idx += kWave) {
             const int g = idx / F, j = idx - g * F;
             int pa = 2 * g, pb = 2 * g + 1;
@@ -167,33 +182,84 @@ score_kernel(const ScoreArgs args) {
             pb = pb > last ? last : pb;
             const int ca = base_class(prof[ref_skew + pa * F + j]);
             const int cb = base_class(prof[ref_skew + pb * F + j]);
-            unsigned char *dst = refc + g * args.refc_stride + 2 * j;
+            unsigned char *dst = refc + g * refc_stride + 2 * j;
             dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? ca - 1 : 4);
             dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? cb - 1 : 4);
+            if (FIND_BAD) {
+                if (ca == 0) atomicMin(&first_bad[2 * (2 * g) + 1], j);
+                if (cb == 0) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
+            }
         }
     }
     __syncthreads();
 
     // ---- query profile: prof[class][pair][lane rows] = S(read base of the row, class) ----
     if (live) {
-        const int last = (int)(pair_end - pair0) - 1;
         for (int idx = lane; idx < geo::kPairs * geo::kRows; idx += kWave) {
             const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
             const int ps = p > last ? last : p;
             int a = 0;
-            if (rr >= pad_rows) a = base_class(rstage[read_skew + ps * R + (rr - pad_rows)]);
+            if (rr >= pad_rows) {
+                a = base_class(rstage[read_skew + ps * R + (rr - pad_rows)]);
+                if (FIND_BAD && a == 0) atomicMin(&first_bad[2 * p], rr - pad_rows);
+            }
             const bool valid = a >= 1 && a <= 4;
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const short s = valid ? (a == c + 1 ? args.match : args.mismatch) : (short)0;
-                *reinterpret_cast<short *>(prof + c * geo::kClassStride + off) = s;
+                const short sc = valid ? (a == c + 1 ? match : mismatch) : (short)0;
+                *reinterpret_cast<short *>(prof + c * geo::kClassStride + off) = sc;
             }
             *reinterpret_cast<short *>(prof + 4 * geo::kClassStride + off) = 0;
         }
     }
     __syncthreads();
-    if (!live) return;
+    w.prof = prof;
+    w.refc = refc;
+    w.first_bad = first_bad;
+    w.pair0 = pair0;
+    w.last = last;
+    return live;
+}
+
+// S[q] (q = 0..K-1): substitution scores of this lane's K rows against the current reference
+// bases of pair A (low halves) and pair B (high halves), from the LDS profile.
+template <int G, int K>
+__device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, int rem_delta, s16x2 (&S)[K]) {
+    using geo = Geo<G, K>;
+#pragma unroll
+    for (int c = 0; c < geo::kChunks; ++c) {
+        const uint2 va = *reinterpret_cast<const uint2 *>(valign_smem + addr_a + c * (G * 8));
+        const uint2 vb = *reinterpret_cast<const uint2 *>(valign_smem + addr_b + c * (G * 8));
+        S[4 * c + 0] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x05040100u));
+        S[4 * c + 1] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x07060302u));
+        S[4 * c + 2] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x05040100u));
+        S[4 * c + 3] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x07060302u));
+    }
+    if (geo::kRem) {
+        const unsigned va = *reinterpret_cast<const unsigned *>(valign_smem + addr_a + rem_delta);
+        const unsigned vb = *reinterpret_cast<const unsigned *>(valign_smem + addr_b + rem_delta);
+        S[K - 2] = as_pk(__builtin_amdgcn_perm(vb, va, 0x05040100u));
+        S[K - 1] = as_pk(__builtin_amdgcn_perm(vb, va, 0x07060302u));
+    }
+}
+
+template <int G, int K, int ALG, bool AFFINE>
+__global__ void __launch_bounds__(256)
+score_kernel(const ScoreArgs args) {
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int F = args.F;
+
+    WaveTables w;
+    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, args.R, F, args.prof_area, args.refc_stride,
+                                 args.wave_lds, args.match, args.mismatch, w))
+        return;
+    unsigned char *prof = w.prof;
+    unsigned char *refc = w.refc;
+    const long long pair0 = w.pair0;
 
     // ---- per-lane constants ----
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;            // group leader: row-0 border
@@ -237,23 +303,8 @@ score_kernel(const ScoreArgs args) {
             const unsigned ca = codes[2 * t], cb = codes[2 * t + 1];
             const unsigned addr_a = lane_a + ca * geo::kClassStride;
             const unsigned addr_b = lane_b + cb * geo::kClassStride;
-            // profile fetch: the K substitution scores of this lane's rows, per pair
             s16x2 S[K];
-#pragma unroll
-            for (int c = 0; c < geo::kChunks; ++c) {
-                const uint2 va = *reinterpret_cast<const uint2 *>(valign_smem + addr_a + c * (G * 8));
-                const uint2 vb = *reinterpret_cast<const uint2 *>(valign_smem + addr_b + c * (G * 8));
-                S[4 * c + 0] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x05040100u));
-                S[4 * c + 1] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x07060302u));
-                S[4 * c + 2] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x05040100u));
-                S[4 * c + 3] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x07060302u));
-            }
-            if (geo::kRem) {
-                const unsigned va = *reinterpret_cast<const unsigned *>(valign_smem + addr_a + rem_delta);
-                const unsigned vb = *reinterpret_cast<const unsigned *>(valign_smem + addr_b + rem_delta);
-                S[K - 2] = as_pk(__builtin_amdgcn_perm(vb, va, 0x05040100u));
-                S[K - 1] = as_pk(__builtin_amdgcn_perm(vb, va, 0x07060302u));
-            }
+            fetch_profile<G, K>(addr_a, addr_b, rem_delta, S);
             // pass 1: everything that only needs the previous column
             s16x2 m[K];
 #pragma unroll
@@ -330,7 +381,7 @@ inline WaveLds wave_lds(int R, int F) {
     w.prof_area = ((w.prof_area + 15) / 16) * 16;
     w.refc_stride = ((2 * F + 15) / 16) * 16;
     const int raw_reads = ((geo::kPairs * R + 16 + 15) / 16) * 16;
-    w.total = w.prof_area + geo::kGroups * w.refc_stride + raw_reads;
+    w.total = w.prof_area + geo::kGroups * w.refc_stride + raw_reads + ((geo::kPairs * 8 + 15) / 16) * 16;
     return w;
 }
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "dp_kernels.hip.h"
+#include "trace_kernels.hip.h"
 
 namespace valign {
 
@@ -35,7 +36,8 @@ inline void hip_check(hipError_t e, const char *what) {
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][2];      // [alg][affine]
+    const void *kernel[2][2];      // score kernels [alg][affine]
+    const void *fill[2];           // alignment fill kernels [alg] (linear gap model)
 };
 
 template <int G, int K>
@@ -44,7 +46,8 @@ constexpr Geometry make_geometry() {
                     {{(const void *)&score_kernel<G, K, kAlgSW, false>,
                       (const void *)&score_kernel<G, K, kAlgSW, true>},
                      {(const void *)&score_kernel<G, K, kAlgNW, false>,
-                      (const void *)&score_kernel<G, K, kAlgNW, true>}}};
+                      (const void *)&score_kernel<G, K, kAlgNW, true>}},
+                    {(const void *)&align_fill_kernel<G, K, kAlgSW>, (const void *)&align_fill_kernel<G, K, kAlgNW>}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -94,6 +97,7 @@ public:
     ~Engine() {
         (void)hipSetDevice(device_);
         release_staging();
+        release_trace_scratch();
         for (int s = 0; s < 2; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
             if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
@@ -183,6 +187,127 @@ public:
         }
     }
 
+
+    // ---- compute_alignments ----
+
+    // Device-resident batch -> rows (n * 2 * (R+F) bytes: read row then ref row, right-justified,
+    // zero before the start, NUL at R+F-1) and idx (n * 4 shorts).  Asynchronous on `stream`;
+    // the pointer scratch is reused chunk after chunk in stream order.
+    void align_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
+                      short *d_idx, hipStream_t stream) {
+        const int alg = opt & 0xF;
+        if (alg > 1 || n <= 0) return;
+        if (sc_.affine)
+            throw std::runtime_error("compute_alignments implements the reference's linear gap model only; "
+                                     "unset the score_gap_open_*/extend_* keys");
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
+        const int blocks8 = (F_ + G - 1 + 7) / 8;
+        const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
+        const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4;
+        long long chunk = (long long)((3ull << 30) / bytes_per_pp) * 2;
+        chunk = std::max(ppb, chunk / ppb * ppb);
+        chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
+        ensure_trace_scratch(chunk, bytes_per_pp, stream);
+        hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
+        const void *fn = plan_.geo->fill[alg];
+        const int block_lds = plan_.lds.total * plan_.waves_per_block;
+        if (block_lds > kDefaultBlockLds)
+            hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        for (long long begin = 0; begin < n; begin += chunk) {
+            const long long cnt = std::min(chunk, n - begin);
+            FillArgs f;
+            f.reads = d_reads + (size_t)begin * R_;
+            f.refs = d_refs + (size_t)begin * F_;
+            f.ptr = d_ptr_;
+            f.ends = d_ends_;
+            f.n = cnt;
+            f.R = R_;
+            f.F = F_;
+            f.prof_area = plan_.lds.prof_area;
+            f.refc_stride = plan_.lds.refc_stride;
+            f.wave_lds = plan_.lds.total;
+            f.blocks8 = blocks8;
+            f.match = (short)sc_.match;
+            f.mismatch = (short)sc_.mismatch;
+            f.gap_read = (short)sc_.gap_read;
+            f.gap_ref = (short)sc_.gap_ref;
+            void *fargs[] = {&f};
+            const long long blocks = (cnt + ppb - 1) / ppb;
+            hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), fargs,
+                                      (size_t)block_lds, stream),
+                      "hipLaunchKernel(align_fill_kernel)");
+            TraceArgs t;
+            t.reads = f.reads;
+            t.refs = f.refs;
+            t.ptr = d_ptr_;
+            t.ends = d_ends_;
+            t.rows = d_rows + (size_t)begin * 2 * AL;
+            t.idx = d_idx + (size_t)begin * 4;
+            t.n = cnt;
+            t.R = R_;
+            t.F = F_;
+            t.G = G;
+            t.K = K;
+            t.pad_rows = G * K - R_;
+            t.blocks8 = blocks8;
+            t.alg = alg;
+            t.match = f.match;
+            t.mismatch = f.mismatch;
+            t.gap_read = f.gap_read;
+            t.gap_ref = f.gap_ref;
+            void *targs[] = {&t};
+            hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
+                                      targs, 0, stream),
+                      "hipLaunchKernel(traceback_kernel)");
+        }
+    }
+
+    // Host pointers in, Alignment[] out: the rows of every pair are fresh operator new[] blocks
+    // (the host's ~Alignment delete[]s them, include/AlignmentKernel.h:20-23).
+    template <typename AlignmentT>
+    void align_host(int opt, int n, const char *const *reads, const char *const *refs, AlignmentT *alignments,
+                    int threads) {
+        const int alg = opt & 0xF;
+        if (alg > 1 || n <= 0) return;
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        const int AL = R_ + F_;
+        const size_t per_pair = (size_t)3 * AL + 8;
+        long long chunk = per_pair ? (long long)((96u << 20) / per_pair) : n;
+        chunk = std::max<long long>(chunk, 1024);
+        chunk = std::min<long long>(chunk, n);
+        ensure_staging(chunk);
+        ensure_align_staging(chunk);
+        if (threads < 1) threads = 1;
+        threads = std::min(threads, 64);
+        auto drain = [&](int s) {
+            if (slot_pending_[s] <= 0) return;
+            scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
+            slot_pending_[s] = 0;
+        };
+        int slot = 0;
+        for (long long begin = 0; begin < n; begin += chunk, slot ^= 1) {
+            const long long cnt = std::min<long long>(chunk, n - begin);
+            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
+            drain(slot);
+            gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
+            hipStream_t st = streams_[0];          // one stream: the pointer scratch is shared
+            hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
+            hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
+            align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], st);
+            hip_check(hipMemcpyAsync(h_rows_[slot], d_rows_[slot], (size_t)cnt * 2 * AL, hipMemcpyDeviceToHost, st), "D2H rows");
+            hip_check(hipMemcpyAsync(h_idx_[slot], d_idx_[slot], sizeof(short) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H idx");
+            hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
+            slot_begin_[slot] = begin;
+            slot_pending_[slot] = cnt;
+        }
+        for (int s = 0; s < 2; ++s) {
+            hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
+            drain(s);
+        }
+    }
+
     std::string describe(int opt, long long n) const {
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
         char buf[512];
@@ -243,6 +368,85 @@ private:
             throw std::runtime_error("no kernel geometry fits read_length=" + std::to_string(R_) + ", ref_length=" +
                                      std::to_string(F_) + " (rows <= 2048 and LDS <= 160 KiB per block are supported)");
         return best;
+    }
+
+
+    void release_trace_scratch() {
+        if (d_ptr_) (void)hipFree(d_ptr_);
+        if (d_ends_) (void)hipFree(d_ends_);
+        d_ptr_ = nullptr;
+        d_ends_ = nullptr;
+        trace_pairs_ = 0;
+        for (int s = 0; s < 2; ++s) {
+            if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
+            if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
+            if (d_rows_[s]) (void)hipFree(d_rows_[s]);
+            if (d_idx_[s]) (void)hipFree(d_idx_[s]);
+            h_rows_[s] = nullptr;
+            h_idx_[s] = nullptr;
+            d_rows_[s] = nullptr;
+            d_idx_[s] = nullptr;
+        }
+        align_staged_pairs_ = 0;
+    }
+
+    void ensure_trace_scratch(long long pairs, size_t bytes_per_pp, hipStream_t stream) {
+        if (pairs <= trace_pairs_) return;
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // nothing may still read the old scratch
+        if (d_ptr_) (void)hipFree(d_ptr_);
+        if (d_ends_) (void)hipFree(d_ends_);
+        d_ptr_ = nullptr;
+        d_ends_ = nullptr;
+        const long long ppw = plan_.pairs_per_wave;
+        const long long waves = (pairs + ppw - 1) / ppw;
+        hip_check(hipMalloc((void **)&d_ptr_, (size_t)(waves * (ppw / 2)) * bytes_per_pp), "hipMalloc(pointer scratch)");
+        hip_check(hipMalloc((void **)&d_ends_, sizeof(EndCell) * (size_t)(waves * ppw)), "hipMalloc(end cells)");
+        trace_pairs_ = pairs;
+    }
+
+    void ensure_align_staging(long long pairs) {
+        if (pairs <= align_staged_pairs_) return;
+        const size_t AL = (size_t)R_ + F_;
+        for (int s = 0; s < 2; ++s) {
+            if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
+            if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
+            if (d_rows_[s]) (void)hipFree(d_rows_[s]);
+            if (d_idx_[s]) (void)hipFree(d_idx_[s]);
+            hip_check(hipHostMalloc((void **)&h_rows_[s], std::max<size_t>((size_t)pairs * 2 * AL, 16), hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc((void **)&h_idx_[s], sizeof(short) * 4 * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipMalloc((void **)&d_rows_[s], std::max<size_t>((size_t)pairs * 2 * AL, 16)), "hipMalloc");
+            hip_check(hipMalloc((void **)&d_idx_[s], sizeof(short) * 4 * (size_t)pairs), "hipMalloc");
+        }
+        align_staged_pairs_ = pairs;
+    }
+
+    template <typename AlignmentT>
+    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) const {
+        const size_t AL = (size_t)R_ + F_;
+        auto work = [=](long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                AlignmentT &a = alignments[i];
+                a.read = new char[AL ? AL : 1];
+                a.ref = new char[AL ? AL : 1];
+                memcpy(a.read, rows + (size_t)i * 2 * AL, AL);
+                memcpy(a.ref, rows + (size_t)i * 2 * AL + AL, AL);
+                a.readStart = idx[4 * i + 0];
+                a.readEnd = idx[4 * i + 1];
+                a.refStart = idx[4 * i + 2];
+                a.refEnd = idx[4 * i + 3];
+            }
+        };
+        if (threads <= 1 || cnt < 2048) {
+            work(0, cnt);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const long long per = (cnt + threads - 1) / threads;
+        for (int t = 0; t < threads; ++t) {
+            const long long lo = t * per, hi = std::min(cnt, lo + per);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto &th : pool) th.join();
     }
 
     void release_staging() {
@@ -309,6 +513,12 @@ private:
     short *h_scores_[2] = {nullptr, nullptr};
     uint8_t *d_reads_[2] = {nullptr, nullptr}, *d_refs_[2] = {nullptr, nullptr};
     int16_t *d_scores_[2] = {nullptr, nullptr};
+    // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
+    unsigned *d_ptr_ = nullptr;
+    EndCell *d_ends_ = nullptr;
+    long long trace_pairs_ = 0, align_staged_pairs_ = 0;
+    uint8_t *h_rows_[2] = {nullptr, nullptr}, *d_rows_[2] = {nullptr, nullptr};
+    short *h_idx_[2] = {nullptr, nullptr}, *d_idx_[2] = {nullptr, nullptr};
 };
 
 }  // namespace valign

@@ -97,9 +97,15 @@ public:
     void compute_alignments(int const &opt, int const &aln_number, char const *const *const reads,
                             char const *const *const refs, Alignment *const alignments) override {
         if ((opt & 0xF) > 1) return;
-        (void)aln_number; (void)reads; (void)refs; (void)alignments;
-        log_line(3, "compute_alignments is not implemented in the HIP backend yet");
-        throw std::runtime_error("HIPKernel::compute_alignments: not implemented yet");
+        const int threads = Parameters.has_key("num_threads") ? Parameters.param_int("num_threads") : 1;
+        log_line(0, "Running HIPKernel align with " + std::to_string(threads) + " host threads on " +
+                        engine_->describe(opt, aln_number));
+        try {
+            engine_->align_host(opt, aln_number, reads, refs, alignments, threads);
+        } catch (const std::exception &e) {
+            log_line(3, e.what());
+            throw;
+        }
     }
 
 private:
@@ -186,6 +192,18 @@ VALIGN_EXPORT int valign_hip_score_device(valign_hip_engine *e, int opt, long lo
     return flat_guard([&] {
         e->impl->score_device(opt, n, (const uint8_t *)d_reads, (const uint8_t *)d_refs, (int16_t *)d_scores,
                               (hipStream_t)hip_stream);
+    });
+}
+
+VALIGN_EXPORT int valign_hip_align_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
+                                          const void *d_refs, void *d_rows, void *d_idx, void *hip_stream) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] {
+        e->impl->align_device(opt, n, (const uint8_t *)d_reads, (const uint8_t *)d_refs, (uint8_t *)d_rows,
+                              (short *)d_idx, (hipStream_t)hip_stream);
     });
 }
 

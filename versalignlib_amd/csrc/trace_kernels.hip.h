@@ -1,0 +1,284 @@
+// trace_kernels.hip.h -- gfx950 kernels for AlignmentKernel::compute_alignments.
+//
+// Reference semantics (restated in oracle/cpu_ref.c):
+//   SW fill + pointers + end cell ... src/Kernels/default/DefaultKernel.cpp:204-280
+//   NW fill + pointers + end cell ... src/Kernels/default/DefaultKernel.cpp:282-389
+//   tracebacks ....................... src/Kernels/default/DefaultKernel.cpp:391-456, 458-525
+//
+// Two kernels:
+//   align_fill_kernel   the score kernel's skewed lane-group sweep (dp_kernels.hip.h) that also
+//                       derives every cell's back pointer with packed int16 arithmetic, packs
+//                       2 bits per cell and streams them to an HBM scratch matrix (8 columns x
+//                       K rows x 2 pairs = K dwords per lane every 8 steps, 16-byte stores),
+//                       and keeps a per-row first-arg-max so that the reference's row-major
+//                       "first strictly greater cell" (SW) and its row-arg-max rule (NW) are
+//                       reproduced exactly from an anti-diagonal sweep.
+//   traceback_kernel    one lane per pair walks the pointers back from the end cell and writes
+//                       the two right-justified gapped rows + the four coordinates.
+//
+// Pointer states stored: 0 DIAG, 1 UP, 2 LEFT (priority DIAG > UP > LEFT as in the reference).
+// START is never stored: for SW the traceback tracks the cell value itself (DIAG subtracts the
+// substitution score, UP/LEFT the gap score) and stops when it reaches 0, which is exactly the
+// reference's "cell == 0 -> START" rule; for NW START is row 0 and column 0 is UP.
+#pragma once
+
+#include "dp_kernels.hip.h"
+
+namespace valign {
+
+struct EndCell {          // per pair, 8 bytes
+    short read_pos;       // 0-based read position of the end cell (-1: empty alignment)
+    short ref_pos;        // 0-based ref position (-1: column 0)
+    short score;          // SW: value of the end cell; NW: unused
+    short pad;
+};
+
+struct FillArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    unsigned *ptr;            // pointer scratch: [pair-of-pairs][lane][block of 8 steps][K] dwords
+    EndCell *ends;            // n
+    long long n;
+    int R, F;
+    int prof_area, refc_stride, wave_lds;
+    int blocks8;              // 8-step blocks per lane = ceil((F + G - 1) / 8)
+    short match, mismatch;
+    short gap_read, gap_ref;
+};
+
+__device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
+    return (s16x2)__builtin_elementwise_min((u16x2)a, (u16x2)b);
+}
+__device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
+    return (s16x2)((u16x2)a * (u16x2)b + (u16x2)c);
+}
+
+template <int G, int K, int ALG>
+__global__ void __launch_bounds__(256)
+align_fill_kernel(const FillArgs args) {
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R, F = args.F;
+    const int pad_rows = geo::kRows - R;
+
+    WaveTables w;
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+                                args.wave_lds, args.match, args.mismatch, w))
+        return;
+
+    const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
+    const unsigned prof_base = (unsigned)(w.prof - valign_smem);
+    const unsigned lane_a = prof_base + (2 * grp) * geo::kPairStride + l * 8;
+    const unsigned lane_b = lane_a + geo::kPairStride;
+    const int rem_delta = geo::kChunks * (G * 8) - l * 4;
+    const unsigned char *codes = w.refc + grp * args.refc_stride - 2 * l;
+
+    const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
+    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
+    const s16x2 one = pk(1), four = pk(4);
+
+    s16x2 Hl[K], code[K], acc[K], rb[K], fc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        short border = 0;
+        if (ALG == kAlgNW) {                      // column 0 of the NW variant: (i) * gap_ref, i 1-based
+            const int p = l * K + q;
+            border = p < pad_rows ? (short)0 : (short)((p - pad_rows + 1) * args.gap_ref);
+        }
+        Hl[q] = pk(border);
+        rb[q] = pk(border);                       // row arg-max seed = the column-0 value (NW) / 0 (SW)
+        fc[q] = pk((short)l);                     // "no cell beat the seed": column index 0
+        code[q] = pk(0);
+        acc[q] = pk(0);
+    }
+    s16x2 h_last = Hl[K - 1];
+    s16x2 up0 = pk(0);
+
+    const long long pp = w.pair0 / 2 + grp;       // pair-of-pairs index of this lane group
+    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+
+    const int steps = args.blocks8 * 8;
+    for (int t = 0; t < steps; ++t) {
+        const s16x2 diag0 = up0;
+        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        const int j = t - l;
+        if ((unsigned)j < (unsigned)F) {
+            const unsigned ca = codes[2 * t], cb = codes[2 * t + 1];
+            const unsigned addr_a = lane_a + ca * geo::kClassStride;
+            const unsigned addr_b = lane_b + cb * geo::kClassStride;
+            s16x2 S[K];
+            fetch_profile<G, K>(addr_a, addr_b, rem_delta, S);
+            const s16x2 tt = pk((short)t);
+            s16x2 dS[K], m[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                dS[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                m[q] = pk_max(dS[q], e);
+            }
+            s16x2 h = up0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 ug = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                h = pk_max(m[q], ug);
+                Hl[q] = h;
+                // back pointer: 0 if h == diag + S, else 1 if h == up + gap_ref, else 2
+                const s16x2 nd = pk_min_u(h - dS[q], one);
+                const s16x2 nu = pk_min_u(h - ug, one);
+                code[q] = pk_mad_u(nd, nu, nd);
+                // per-row first arg-max (strictly greater wins, so the first column is kept)
+                const s16x2 nb = pk_max(rb[q], h);
+                const s16x2 changed = (rb[q] - nb) >> 15;         // 0xFFFF where the row best rose
+                fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                rb[q] = nb;
+            }
+            h_last = h;
+        }
+        // pointer accumulators shift every step in every lane, so that bit positions depend on
+        // t only; columns outside [0, F) leave don't-care bits that are never read back
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
+        if ((t & 7) == 7) {
+            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
+#pragma unroll
+            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+        }
+    }
+
+    // ---- end cell of each of the two pairs of this group ----
+    const int base_lane = lane - l;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const long long pair = w.pair0 + 2 * grp + half;
+        EndCell out;
+        out.pad = 0;
+        if (ALG == kAlgSW) {
+            int bv = 0, bq = 0, bcol = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int v = half ? rb[q].y : rb[q].x;
+                const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
+                if (v > bv) {
+                    bv = v;
+                    bq = q;
+                    bcol = c;
+                }
+            }
+            // larger value first, then smaller row: rows are unique per lane so keys are too
+            unsigned key = ((unsigned)bv << 16) | (unsigned)(0xFFFF - (l * K + bq));
+            unsigned kmax = key;
+#pragma unroll
+            for (int d = G / 2; d >= 1; d >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)kmax, d, kWave);
+                kmax = other > kmax ? other : kmax;
+            }
+            const int p = 0xFFFF - (int)(kmax & 0xFFFF);
+            const int win_lane = p / K;
+            const int col_t = __shfl(bcol, base_lane + win_lane, kWave);
+            out.score = (short)(kmax >> 16);
+            out.read_pos = (short)(p - pad_rows);
+            out.ref_pos = (short)(col_t - win_lane);
+            if (out.score <= 0) {
+                out.read_pos = 0;
+                out.ref_pos = 0;
+            }
+        } else {
+            const int p_local = 2 * grp + half;
+            const int ir = w.first_bad[2 * (p_local > w.last ? w.last : p_local)];
+            const int jr = w.first_bad[2 * (p_local > w.last ? w.last : p_local) + 1];
+            const int i_end = ir - 1;                    // last valid read position (may be -1)
+            int arg_col = 0;
+            if (i_end >= 0) {
+                const int p = i_end + pad_rows;
+                const int src_l = p / K, src_q = p % K;
+                int mine = 0;
+#pragma unroll
+                for (int q = 0; q < K; ++q)
+                    if (q == src_q) mine = ((half ? fc[q].y : fc[q].x) & 0xFFFF) - l;
+                arg_col = __shfl(mine, base_lane + src_l, kWave);
+            }
+            const int last_ref = jr - 1;
+            out.score = 0;
+            out.read_pos = (short)i_end;
+            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+        }
+        if (l == 0 && pair < args.n) args.ends[pair] = out;
+    }
+}
+
+struct TraceArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    const unsigned *ptr;
+    const EndCell *ends;
+    uint8_t *rows;            // n * 2 * (R+F), pre-zeroed
+    short *idx;               // n * 4: readStart, readEnd, refStart, refEnd
+    long long n;
+    int R, F;
+    int G, K, pad_rows, blocks8;
+    int alg;
+    short match, mismatch, gap_read, gap_ref;
+};
+
+__global__ void __launch_bounds__(256)
+traceback_kernel(const TraceArgs a) {
+    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n) return;
+    const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
+    const uint8_t *read = a.reads + pair * R;
+    const uint8_t *ref = a.refs + pair * F;
+    uint8_t *row_read = a.rows + pair * 2 * AL;
+    uint8_t *row_ref = row_read + AL;
+    const EndCell e = a.ends[pair];
+    const unsigned *ptr_pair = a.ptr + ((pair >> 1) * G) * (long long)a.blocks8 * K;
+    const int half_shift = (int)(pair & 1) * 16;
+
+    int i = e.read_pos, j = e.ref_pos, h = e.score;
+    int k = AL - 2;
+    while (k >= 0) {
+        int move;                                   // 0 DIAG, 1 UP, 2 LEFT
+        if (a.alg == kAlgSW) {
+            if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
+        } else {
+            if (i < 0) break;                       // row 0: START
+        }
+        if (j < 0) {
+            move = 1;                               // column 0 of the NW variant: UP
+        } else {
+            const int p = i + a.pad_rows;
+            const int l = p / K, q = p - l * K;
+            const int t = j + l;
+            const unsigned word = ptr_pair[((long long)l * a.blocks8 + (t >> 3)) * K + q];
+            move = (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
+        }
+        if (move == 0) {
+            const uint8_t cr = read[i], cf = ref[j];
+            row_read[k] = cr;
+            row_ref[k] = cf;
+            const int ca = base_class(cr), cb = base_class(cf);
+            if (ca >= 1 && ca <= 4 && cb >= 1 && cb <= 4) h -= (ca == cb ? a.match : a.mismatch);
+            --i;
+            --j;
+        } else if (move == 1) {
+            row_read[k] = read[i];
+            row_ref[k] = '-';
+            h -= a.gap_ref;
+            --i;
+        } else {
+            row_read[k] = '-';
+            row_ref[k] = ref[j];
+            h -= a.gap_read;
+            --j;
+        }
+        --k;
+    }
+    short *out = a.idx + pair * 4;
+    out[0] = (short)(k + 1);
+    out[1] = (short)(AL - 1);
+    out[2] = (short)(k + 1);
+    out[3] = (short)(AL - 1);
+}
+
+}  // namespace valign

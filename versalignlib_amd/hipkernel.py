@@ -60,6 +60,7 @@ def lib():
         L.valign_hip_engine_destroy.restype = None
         L.valign_hip_engine_destroy.argtypes = [vp]
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
+        L.valign_hip_align_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp, vp]
         L.valign_hip_score_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int]
         L.valign_hip_describe.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_char_p,
                                           ctypes.c_int]
@@ -71,7 +72,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_score_device", "valign_hip_score_host", "valign_hip_describe",
+    "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -112,6 +113,24 @@ class Engine:
         if rc != 0:
             raise HipKernelError(_err())
         return scores
+
+    def align_device(self, opt, reads, refs, rows=None, idx=None, stream=None):
+        """-> rows uint8 CUDA [n, 2, R+F], idx int16 CUDA [n, 4] (async on the current stream)."""
+        import torch
+        n = reads.shape[0]
+        assert reads.is_cuda and refs.is_cuda and reads.is_contiguous() and refs.is_contiguous()
+        assert tuple(reads.shape) == (n, self.read_length) and tuple(refs.shape) == (n, self.ref_length)
+        AL = self.read_length + self.ref_length
+        if rows is None:
+            rows = torch.empty((n, 2, AL), dtype=torch.uint8, device=reads.device)
+        if idx is None:
+            idx = torch.empty((n, 4), dtype=torch.int16, device=reads.device)
+        st = stream if stream is not None else torch.cuda.current_stream(reads.device)
+        rc = lib().valign_hip_align_device(self._h, int(opt), n, reads.data_ptr(), refs.data_ptr(),
+                                           rows.data_ptr(), idx.data_ptr(), st.cuda_stream)
+        if rc != 0:
+            raise HipKernelError(_err())
+        return rows, idx
 
     def describe(self, opt=0, n=0):
         buf = ctypes.create_string_buffer(1024)
