@@ -1,0 +1,46 @@
+"""Time compute_alignments' device path (fill + traceback) on the bench batch (developer tool)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from versalignlib_amd import hipkernel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1 << 20)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--geoms", default="0x0")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    reads, refs = bench.synth_on_device(a.pairs, dev, seed=2000)
+    AL = bench.R + bench.F
+    rows = torch.empty((a.pairs, 2, AL), dtype=torch.uint8, device=dev)
+    idx = torch.empty((a.pairs, 4), dtype=torch.int16, device=dev)
+    for geom in a.geoms.split(","):
+        G, K = (int(x) for x in geom.split("x"))
+        eng = hipkernel.Engine(bench.R, bench.F, group_lanes=G, rows_per_lane=K)
+        for opt, name in ((0, "sw"), (1, "nw")):
+            eng.align_device(opt, reads, refs, rows, idx)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                eng.align_device(opt, reads, refs, rows, idx)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            d = eng.describe(opt, a.pairs)
+            print(json.dumps({"mode": name + "_align", "geom": "%dx%d" % (d["group_lanes"], d["rows_per_lane"]),
+                              "ms": round(ms, 3), "gcups": round(a.pairs * bench.R * bench.F / ms / 1e6, 1),
+                              "start_checksum": int(idx[:, 0].to(torch.int64).sum().item())}))
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()
