@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace valign {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -91,16 +93,14 @@ struct Geo {
     static constexpr int kGroups = kWave / G;        // lane groups per wave
     static constexpr int kPairs = 2 * kGroups;       // pairs per wave
     static constexpr int kRows = G * K;              // padded rows
-    static constexpr int kChunks = K / 4;            // 4-row chunks read as b64
-    static constexpr int kRem = K % 4;               // 0 or 2 rows read as b32
+    static constexpr int kLaneBytes = K * 2;         // one lane's K int16 scores, contiguous
     static constexpr int kPairStride = kRows * 2;    // bytes of one (class, pair) array
-    static constexpr int kClassStride = kPairs * kPairStride;
-    static constexpr int kProfBytes = 5 * kClassStride;
+    // profile slabs: slab (class * kPairs + pair) for classes 0..3, plus ONE all-zero slab
+    // shared by every pair for "this reference base scores nothing"
+    static constexpr int kZeroSlab = 4 * kPairs;
+    static constexpr int kProfBytes = (4 * kPairs + 1) * kPairStride;
     // byte offset of row q of lane l inside one (class, pair) array
-    __host__ __device__ static constexpr int row_offset(int l, int q) {
-        return q < 4 * kChunks ? (q / 4) * (G * 8) + l * 8 + (q % 4) * 2
-                               : kChunks * (G * 8) + l * 4 + (q - 4 * kChunks) * 2;
-    }
+    __host__ __device__ static constexpr int row_offset(int l, int q) { return l * kLaneBytes + q * 2; }
 };
 
 // Copy global bytes [begin, end) of `src` into LDS so that byte x lands at
@@ -125,16 +125,17 @@ extern __shared__ __align__(16) unsigned char valign_smem[];
 
 // Per-wave LDS tables shared by the score and the alignment-fill kernels.
 struct WaveTables {
-    unsigned char *prof;    // [5 classes][pairs][lane rows] int16 substitution scores
-    unsigned char *refc;    // [groups][2 * F] class codes, pair A / pair B interleaved
+    unsigned char *prof;    // [4 classes x pairs + 1 zero slab][lane rows] int16 substitution scores
+    unsigned char *refc;    // [groups][2 * F] profile slab numbers, pair A / pair B interleaved
     int *first_bad;         // [pairs][2]: first read / ref position whose class is 0 (else R / F)
     long long pair0;        // first pair of this wave
     int last;               // index of the last existing pair of the wave (tail waves are short)
 };
 
-// Stage the wave's raw reads/refs with coalesced 16-byte loads, then build the class-code
-// arrays and the query profile.  Returns false for a wave past the end of the batch
-// (it still takes part in the block barriers).
+// Stage the wave's raw refs with coalesced 16-byte loads, then build the per-column slab
+// numbers and the query profile (read bases come straight from HBM, one coalesced byte
+// per lane and row).  Returns false for a wave past the end of the batch (it still takes
+// part in the block barriers).
 template <int G, int K, bool FIND_BAD>
 __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
                                            int prof_area, int refc_stride, int wave_lds, short match,
@@ -147,8 +148,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     unsigned char *lds = valign_smem + (size_t)wave * wave_lds;
     unsigned char *prof = lds;
     unsigned char *refc = lds + prof_area;
-    unsigned char *rstage = refc + geo::kGroups * refc_stride;   // raw reads of the wave
-    int *first_bad = reinterpret_cast<int *>(lds + wave_lds - geo::kPairs * 8);
+    int *first_bad = reinterpret_cast<int *>(refc + geo::kGroups * refc_stride);
 
     const int waves = blockDim.x / kWave;
     const long long pair0 = ((long long)blockIdx.x * waves + wave) * geo::kPairs;
@@ -157,13 +157,21 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     if (pair_end > n) pair_end = n;
     const int last = (int)(pair_end - pair0) - 1;
 
-    // ---- stage raw bytes: refs into the (not yet built) profile area, reads beside ----
-    long long ref_lo = 0, read_lo = 0;
+    // ---- read bases of this lane's 2K (pair, padded row) items, straight from HBM ----
+    // kPairs * kRows == 128 * K for every geometry, so each lane owns exactly 2K items.
+    unsigned char rd[2 * K];
+    long long ref_lo = 0;
     if (live) {
+#pragma unroll
+        for (int i = 0; i < 2 * K; ++i) {
+            const int idx = lane + kWave * i;
+            const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
+            const int ps = p > last ? last : p;
+            rd[i] = rr >= pad_rows ? reads[(pair0 + ps) * R + (rr - pad_rows)] : (unsigned char)0;
+        }
+        // ---- raw refs into the (not yet built) profile area ----
         ref_lo = pair0 * F;
-        read_lo = pair0 * R;
         stage_span(prof, refs, ref_lo, pair_end * F, lane);
-        stage_span(rstage, reads, read_lo, pair_end * R, lane);
         if (FIND_BAD && lane < geo::kPairs) {
             first_bad[2 * lane] = R;
             first_bad[2 * lane + 1] = F;
@@ -171,9 +179,8 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     }
     __syncthreads();
     const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
-    const int read_skew = (int)((unsigned long long)(reads + read_lo) & 15ull);
 
-    // ---- reference bases -> profile class (0..3 = A,T,C,G; 4 = scores nothing) ----
+    // ---- reference bases -> profile slab of the pair (class * kPairs + pair, or the zero slab) ----
     if (live) {
         for (int idx = lane; idx < geo::kGroups * F; idx += kWave) {
             const int g = idx / F, j = idx - g * F;
@@ -183,8 +190,8 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             const int ca = base_class(prof[ref_skew + pa * F + j]);
             const int cb = base_class(prof[ref_skew + pb * F + j]);
             unsigned char *dst = refc + g * refc_stride + 2 * j;
-            dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? ca - 1 : 4);
-            dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? cb - 1 : 4);
+            dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab);
+            dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab);
             if (FIND_BAD) {
                 if (ca == 0) atomicMin(&first_bad[2 * (2 * g) + 1], j);
                 if (cb == 0) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
@@ -193,25 +200,24 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     }
     __syncthreads();
 
-    // ---- query profile: prof[class][pair][lane rows] = S(read base of the row, class) ----
+    // ---- query profile: slab[class * kPairs + pair][lane rows] = S(read base of the row, class) ----
     if (live) {
-        for (int idx = lane; idx < geo::kPairs * geo::kRows; idx += kWave) {
+#pragma unroll
+        for (int i = 0; i < 2 * K; ++i) {
+            const int idx = lane + kWave * i;
             const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
-            const int ps = p > last ? last : p;
-            int a = 0;
-            if (rr >= pad_rows) {
-                a = base_class(rstage[read_skew + ps * R + (rr - pad_rows)]);
-                if (FIND_BAD && a == 0) atomicMin(&first_bad[2 * p], rr - pad_rows);
-            }
+            const int a = rr >= pad_rows ? base_class(rd[i]) : 0;
+            if (FIND_BAD && rr >= pad_rows && a == 0) atomicMin(&first_bad[2 * p], rr - pad_rows);
             const bool valid = a >= 1 && a <= 4;
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const short sc = valid ? (a == c + 1 ? match : mismatch) : (short)0;
-                *reinterpret_cast<short *>(prof + c * geo::kClassStride + off) = sc;
+                *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
             }
-            *reinterpret_cast<short *>(prof + 4 * geo::kClassStride + off) = 0;
         }
+        for (int idx = lane; idx < geo::kPairStride / 4; idx += kWave)
+            reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = 0u;
     }
     __syncthreads();
     w.prof = prof;
@@ -222,32 +228,66 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     return live;
 }
 
-// S[q] (q = 0..K-1): substitution scores of this lane's K rows against the current reference
-// bases of pair A (low halves) and pair B (high halves), from the LDS profile.
-template <int G, int K>
-__device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, int rem_delta, s16x2 (&S)[K]) {
-    using geo = Geo<G, K>;
+typedef __attribute__((address_space(3))) const unsigned lds_cu32;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8;
+
+// LDS byte offset of a pointer into the dynamic shared array
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// K/2 dwords starting at LDS byte offset `addr`, with the widest loads the lane stride allows
+template <int K>
+__device__ __forceinline__ void lds_load_lane(unsigned addr, unsigned (&v)[K / 2]) {
+    constexpr int N = K / 2;
+    if constexpr ((K * 2) % 16 == 0) {
 #pragma unroll
-    for (int c = 0; c < geo::kChunks; ++c) {
-        const uint2 va = *reinterpret_cast<const uint2 *>(valign_smem + addr_a + c * (G * 8));
-        const uint2 vb = *reinterpret_cast<const uint2 *>(valign_smem + addr_b + c * (G * 8));
-        S[4 * c + 0] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x05040100u));
-        S[4 * c + 1] = as_pk(__builtin_amdgcn_perm(vb.x, va.x, 0x07060302u));
-        S[4 * c + 2] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x05040100u));
-        S[4 * c + 3] = as_pk(__builtin_amdgcn_perm(vb.y, va.y, 0x07060302u));
-    }
-    if (geo::kRem) {
-        const unsigned va = *reinterpret_cast<const unsigned *>(valign_smem + addr_a + rem_delta);
-        const unsigned vb = *reinterpret_cast<const unsigned *>(valign_smem + addr_b + rem_delta);
-        S[K - 2] = as_pk(__builtin_amdgcn_perm(vb, va, 0x05040100u));
-        S[K - 1] = as_pk(__builtin_amdgcn_perm(vb, va, 0x07060302u));
+        for (int i = 0; i < N / 4; ++i) {
+            const u32x4 x = *(lds_cu32x4 *)(addr + 16 * i);
+            v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+        }
+    } else if constexpr ((K * 2) % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const u32x2 x = *(lds_cu32x2 *)(addr + 8 * i);
+            v[2 * i] = x.x; v[2 * i + 1] = x.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = *(lds_cu32 *)(addr + 4 * i);
     }
 }
 
-template <int G, int K, int ALG, bool AFFINE>
+// S[q] (q = 0..K-1): substitution scores of this lane's K rows against the current reference
+// bases of pair A (low halves) and pair B (high halves), from the LDS profile.
+template <int G, int K>
+__device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, s16x2 (&S)[K]) {
+    unsigned va[K / 2], vb[K / 2];
+    lds_load_lane<K>(addr_a, va);
+    lds_load_lane<K>(addr_b, vb);
+#pragma unroll
+    for (int c = 0; c < K / 2; ++c) {
+        S[2 * c + 0] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x05040100u));
+        S[2 * c + 1] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x07060302u));
+    }
+}
+
+// GAPS selects the recurrence: kGapLinear (two gap scores), kGapSym (linear with
+// gap_read == gap_ref: one subtract serves both neighbours), kGapAffine (Gotoh extension).
+constexpr int kGapLinear = 0;
+constexpr int kGapSym = 1;
+constexpr int kGapAffine = 2;
+
+template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
     using geo = Geo<G, K>;
+    constexpr bool AFFINE = GAPS == kGapAffine;
+    constexpr bool SYM = GAPS == kGapSym;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
     const int l = lane % G;
@@ -257,17 +297,12 @@ score_kernel(const ScoreArgs args) {
     if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, args.R, F, args.prof_area, args.refc_stride,
                                  args.wave_lds, args.match, args.mismatch, w))
         return;
-    unsigned char *prof = w.prof;
-    unsigned char *refc = w.refc;
     const long long pair0 = w.pair0;
 
-    // ---- per-lane constants ----
+    // ---- per-lane constants (LDS byte offsets) ----
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;            // group leader: row-0 border
-    const unsigned prof_base = (unsigned)(prof - valign_smem);
-    const unsigned lane_a = prof_base + (2 * grp) * geo::kPairStride + l * 8;
-    const unsigned lane_b = lane_a + geo::kPairStride;
-    const int rem_delta = geo::kChunks * (G * 8) - l * 4;        // b32 tail chunk: lane stride 4
-    const unsigned char *codes = refc + grp * args.refc_stride - 2 * l;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;     // + slab * kPairStride
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;   // + 2 per step
 
     s16x2 g_read, g_ref, o_read, e_read, o_ref, e_ref;
     if (ALG == kAlgSW) {           // magnitudes for the unsigned floor-at-zero subtract
@@ -288,58 +323,94 @@ score_kernel(const ScoreArgs args) {
         El[q] = border_f;
     }
     s16x2 up0 = pk(0), h_last = pk(0), f_last = border_f, best = pk(0), row_best = pk(0);
+    int j = -l;                                                  // this lane's column at step t
 
-    const int steps = F + G - 1;
-    for (int t = 0; t < steps; ++t) {
+    // One step of the skewed sweep.  MASKED steps EXEC-mask lanes whose column is outside
+    // [0, F) (pipeline fill and drain); in the steady phase every lane is inside.
+    auto step = [&](auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        if (G == 16) {             // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
+            up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
+        } else {
+            up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        }
         s16x2 fup0 = border_f;
         if (AFFINE) {
             const unsigned fv = from_prev_lane(as_u32(f_last));
             fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
         }
-        const int j = t - l;
-        if ((unsigned)j < (unsigned)F) {
-            const unsigned ca = codes[2 * t], cb = codes[2 * t + 1];
-            const unsigned addr_a = lane_a + ca * geo::kClassStride;
-            const unsigned addr_b = lane_b + cb * geo::kClassStride;
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            const unsigned addr_a = lane_base + ca * geo::kPairStride;
+            const unsigned addr_b = lane_base + cb * geo::kPairStride;
             s16x2 S[K];
-            fetch_profile<G, K>(addr_a, addr_b, rem_delta, S);
-            // pass 1: everything that only needs the previous column
-            s16x2 m[K];
+            fetch_profile<G, K>(addr_a, addr_b, S);
+            if (SYM) {
+                // h = max(diag + S, max(left, up) - g): one subtract for both gap directions
+                s16x2 d[K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                s16x2 e;
-                if (AFFINE) {
-                    e = (ALG == kAlgSW)
-                            ? pk_max(pk_sub_floor0(El[q], e_read), pk_sub_floor0(Hl[q], o_read))
-                            : pk_max(pk_add_sat(El[q], e_read), pk_add_sat(Hl[q], o_read));
-                    El[q] = e;
-                } else {
-                    e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                for (int q = 0; q < K; ++q) {
+                    d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                    if (ALG == kAlgSW) best = pk_max(best, d[q]);   // the maximum is always a diagonal arrival
                 }
-                m[q] = pk_max(d, e);
-            }
-            // pass 2: the in-lane chain down the column
-            s16x2 h = up0, f = fup0;
+                s16x2 h = up0;
 #pragma unroll
-            for (int q = 0; q < K; ++q) {
-                if (AFFINE) {
-                    f = (ALG == kAlgSW) ? pk_max(pk_sub_floor0(f, e_ref), pk_sub_floor0(h, o_ref))
-                                        : pk_max(pk_add_sat(f, e_ref), pk_add_sat(h, o_ref));
-                } else {
-                    f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                for (int q = 0; q < K; ++q) {
+                    const s16x2 x = pk_max(Hl[q], h);
+                    const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
+                    h = pk_max(d[q], y);
+                    Hl[q] = h;
                 }
-                h = pk_max(m[q], f);
-                Hl[q] = h;
-                if (ALG == kAlgSW) best = pk_max(best, h);
+                h_last = h;
+            } else {
+                // pass 1: everything that only needs the previous column
+                s16x2 m[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                    s16x2 e;
+                    if (AFFINE) {
+                        e = (ALG == kAlgSW)
+                                ? pk_max(pk_sub_floor0(El[q], e_read), pk_sub_floor0(Hl[q], o_read))
+                                : pk_max(pk_add_sat(El[q], e_read), pk_add_sat(Hl[q], o_read));
+                        El[q] = e;
+                    } else {
+                        e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                    }
+                    m[q] = pk_max(d, e);
+                    if (ALG == kAlgSW) best = pk_max(best, d);
+                }
+                // pass 2: the in-lane chain down the column
+                s16x2 h = up0, f = fup0;
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    if (AFFINE) {
+                        f = (ALG == kAlgSW) ? pk_max(pk_sub_floor0(f, e_ref), pk_sub_floor0(h, o_ref))
+                                            : pk_max(pk_add_sat(f, e_ref), pk_add_sat(h, o_ref));
+                    } else {
+                        f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                    }
+                    h = pk_max(m[q], f);
+                    Hl[q] = h;
+                }
+                h_last = h;
+                f_last = f;
             }
-            h_last = h;
-            f_last = f;
-            if (ALG == kAlgNW) row_best = pk_max(row_best, h);
+            if (ALG == kAlgNW) row_best = pk_max(row_best, h_last);
         }
-    }
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = F + G - 1;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{});
+#pragma unroll 2
+    for (; t < steady_end; ++t) step(std::false_type{});
+    for (; t < steps; ++t) step(std::true_type{});
 
     // ---- result ----
     s16x2 res;
@@ -380,8 +451,7 @@ inline WaveLds wave_lds(int R, int F) {
     w.prof_area = geo::kProfBytes > raw_refs ? geo::kProfBytes : raw_refs;
     w.prof_area = ((w.prof_area + 15) / 16) * 16;
     w.refc_stride = ((2 * F + 15) / 16) * 16;
-    const int raw_reads = ((geo::kPairs * R + 16 + 15) / 16) * 16;
-    w.total = w.prof_area + geo::kGroups * w.refc_stride + raw_reads + ((geo::kPairs * 8 + 15) / 16) * 16;
+    w.total = w.prof_area + geo::kGroups * w.refc_stride + ((geo::kPairs * 8 + 15) / 16) * 16;
     return w;
 }
 

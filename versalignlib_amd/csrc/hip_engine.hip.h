@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -36,17 +37,19 @@ inline void hip_check(hipError_t e, const char *what) {
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][2];      // score kernels [alg][affine]
+    const void *kernel[2][3];      // score kernels [alg][linear, symmetric linear, affine]
     const void *fill[2];           // alignment fill kernels [alg] (linear gap model)
 };
 
 template <int G, int K>
 constexpr Geometry make_geometry() {
     return Geometry{G, K, &wave_lds<G, K>,
-                    {{(const void *)&score_kernel<G, K, kAlgSW, false>,
-                      (const void *)&score_kernel<G, K, kAlgSW, true>},
-                     {(const void *)&score_kernel<G, K, kAlgNW, false>,
-                      (const void *)&score_kernel<G, K, kAlgNW, true>}},
+                    {{(const void *)&score_kernel<G, K, kAlgSW, kGapLinear>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapSym>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>},
+                     {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>}},
                     {(const void *)&align_fill_kernel<G, K, kAlgSW>, (const void *)&align_fill_kernel<G, K, kAlgNW>}};
 }
 
@@ -132,7 +135,8 @@ public:
         a.ext_read = (short)sc_.ext_read;
         a.open_ref = (short)sc_.open_ref;
         a.ext_ref = (short)sc_.ext_ref;
-        const void *fn = plan_.geo->kernel[alg][sc_.affine ? 1 : 0];
+        const int gaps = sc_.affine ? kGapAffine : (sc_.gap_read == sc_.gap_ref && !no_sym_ ? kGapSym : kGapLinear);
+        const void *fn = plan_.geo->kernel[alg][gaps];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -351,14 +355,34 @@ private:
             p.geo = &g;
             p.lds = g.lds(R_, F_);
             p.pairs_per_wave = 2 * (kWave / g.G);
-            p.waves_per_block = 4;
-            while (p.waves_per_block > 1 && p.lds.total * p.waves_per_block > kDefaultBlockLds) p.waves_per_block >>= 1;
-            if (p.lds.total * p.waves_per_block > kMaxBlockLds) continue;
+            // Block size: 4-wave blocks put one wave on each SIMD and measured fastest whenever two
+            // of them fit a CU's 160 KiB of LDS; otherwise take the size that keeps most waves resident.
+            int best_waves = 0;
+            if (p.lds.total * 8 <= kMaxBlockLds) {
+                p.waves_per_block = 4;
+                best_waves = std::min(32, (kMaxBlockLds / (p.lds.total * 4)) * 4);
+            } else {
+                for (int wpb = 4; wpb >= 1; wpb >>= 1) {
+                    if (p.lds.total * wpb > kMaxBlockLds) continue;
+                    const int resident = std::min(32, (kMaxBlockLds / (p.lds.total * wpb)) * wpb);
+                    if (resident > best_waves) {
+                        best_waves = resident;
+                        p.waves_per_block = wpb;
+                    }
+                }
+            }
+            if (const char *force = getenv("VALIGN_HIP_WPB")) {                 // tuning switch
+                const int wpb = atoi(force);
+                if ((wpb == 1 || wpb == 2 || wpb == 4) && p.lds.total * wpb <= kMaxBlockLds) {
+                    p.waves_per_block = wpb;
+                    best_waves = std::min(32, (kMaxBlockLds / (p.lds.total * wpb)) * wpb);
+                }
+            }
+            if (best_waves == 0) continue;
             // lane-steps per pair, weighted by instructions per step (per-row work + fixed part)
             const double per_step = g.K * (sc_.affine ? 11.0 : 7.0) + 14.0;
             double cost = (double)(F_ + g.G - 1) * per_step * g.G / 2.0;
-            const int waves_per_cu = std::min(16, kMaxBlockLds / std::max(1, p.lds.total));
-            if (waves_per_cu < 8) cost *= 1.0 + 0.15 * (8 - waves_per_cu);      // too few waves to fill the SIMDs
+            if (best_waves < 8) cost *= 1.0 + 0.08 * (8 - best_waves);         // fewer than two waves per SIMD
             if (!best.geo || cost < best_cost) {
                 best = p;
                 best_cost = cost;
@@ -503,6 +527,7 @@ private:
 
     int device_, R_, F_;
     Scoring sc_;
+    bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     std::string arch_;
     LaunchPlan plan_;
     hipStream_t streams_[2] = {nullptr, nullptr};

@@ -69,10 +69,7 @@ align_fill_kernel(const FillArgs args) {
         return;
 
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
-    const unsigned prof_base = (unsigned)(w.prof - valign_smem);
-    const unsigned lane_a = prof_base + (2 * grp) * geo::kPairStride + l * 8;
-    const unsigned lane_b = lane_a + geo::kPairStride;
-    const int rem_delta = geo::kChunks * (G * 8) - l * 4;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
     const unsigned char *codes = w.refc + grp * args.refc_stride - 2 * l;
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
@@ -106,10 +103,10 @@ align_fill_kernel(const FillArgs args) {
         const int j = t - l;
         if ((unsigned)j < (unsigned)F) {
             const unsigned ca = codes[2 * t], cb = codes[2 * t + 1];
-            const unsigned addr_a = lane_a + ca * geo::kClassStride;
-            const unsigned addr_b = lane_b + cb * geo::kClassStride;
+            const unsigned addr_a = lane_base + ca * geo::kPairStride;
+            const unsigned addr_b = lane_base + cb * geo::kPairStride;
             s16x2 S[K];
-            fetch_profile<G, K>(addr_a, addr_b, rem_delta, S);
+            fetch_profile<G, K>(addr_a, addr_b, S);
             const s16x2 tt = pk((short)t);
             s16x2 dS[K], m[K];
 #pragma unroll
