@@ -136,3 +136,19 @@ def test_full_size_properties_config2():
         assert (got == got[0]).all()
         assert np.array_equal(got[0], cpu_ref.score(opt, reads, refs, threads=8))
     eng.close()
+
+
+@pytest.mark.parametrize("aff", [(-5, -1, -5, -1), (-7, -2, -7, -2), (-4, -4, -4, -4), (-5, -1, -5, -2)])
+def test_symmetric_and_asymmetric_affine_kernels(aff):
+    """open_read == open_ref and ext_read == ext_ref selects the shared-subtract kernel variant;
+    both variants must equal the affine oracle."""
+    R, F, n = 150, 500, 515
+    reads, refs = _data(R, F, n, 71)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1],
+                score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.score_alignments(opt, reads, refs)
+            exp = cpu_ref.score(opt, reads, refs, sc, threads=8, affine=True)
+            assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])

@@ -281,13 +281,15 @@ __device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, 
 constexpr int kGapLinear = 0;
 constexpr int kGapSym = 1;
 constexpr int kGapAffine = 2;
+constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_read == ext_ref
 
 template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
     using geo = Geo<G, K>;
-    constexpr bool AFFINE = GAPS == kGapAffine;
+    constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym;
     constexpr bool SYM = GAPS == kGapSym;
+    constexpr bool AFFSYM = GAPS == kGapAffineSym;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
     const int l = lane % G;
@@ -316,11 +318,16 @@ score_kernel(const ScoreArgs args) {
     }
     const s16x2 border_f = pk(ALG == kAlgNW ? kNegInf : (short)0);
 
-    s16x2 Hl[K], El[K];
+    // Hl: H of the previous column; El: E of the previous column; HOl (symmetric affine only):
+    // H - open of the previous column, which feeds E of this column (and, within a column, F of
+    // the next row), so the subtract is done once per cell instead of twice.
+    s16x2 Hl[K], El[K], HOl[K];
+    const s16x2 ho_border = (ALG == kAlgSW) ? pk(0) : o_ref;      // border H (= 0) minus open
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         Hl[q] = pk(0);
         El[q] = border_f;
+        HOl[q] = ho_border;
     }
     s16x2 up0 = pk(0), h_last = pk(0), f_last = border_f, best = pk(0), row_best = pk(0);
     int j = -l;                                                  // this lane's column at step t
@@ -370,7 +377,10 @@ score_kernel(const ScoreArgs args) {
                 for (int q = 0; q < K; ++q) {
                     const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
                     s16x2 e;
-                    if (AFFINE) {
+                    if (AFFSYM) {
+                        e = pk_max((ALG == kAlgSW) ? pk_sub_floor0(El[q], e_read) : pk_add_sat(El[q], e_read), HOl[q]);
+                        El[q] = e;
+                    } else if (AFFINE) {
                         e = (ALG == kAlgSW)
                                 ? pk_max(pk_sub_floor0(El[q], e_read), pk_sub_floor0(Hl[q], o_read))
                                 : pk_max(pk_add_sat(El[q], e_read), pk_add_sat(Hl[q], o_read));
@@ -383,9 +393,13 @@ score_kernel(const ScoreArgs args) {
                 }
                 // pass 2: the in-lane chain down the column
                 s16x2 h = up0, f = fup0;
+                s16x2 ho = pk(0);
+                if (AFFSYM) ho = (ALG == kAlgSW) ? pk_sub_floor0(up0, o_ref) : pk_add_sat(up0, o_ref);
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
-                    if (AFFINE) {
+                    if (AFFSYM) {
+                        f = pk_max((ALG == kAlgSW) ? pk_sub_floor0(f, e_ref) : pk_add_sat(f, e_ref), ho);
+                    } else if (AFFINE) {
                         f = (ALG == kAlgSW) ? pk_max(pk_sub_floor0(f, e_ref), pk_sub_floor0(h, o_ref))
                                             : pk_max(pk_add_sat(f, e_ref), pk_add_sat(h, o_ref));
                     } else {
@@ -393,6 +407,10 @@ score_kernel(const ScoreArgs args) {
                     }
                     h = pk_max(m[q], f);
                     Hl[q] = h;
+                    if (AFFSYM) {
+                        ho = (ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref);
+                        HOl[q] = ho;
+                    }
                 }
                 h_last = h;
                 f_last = f;

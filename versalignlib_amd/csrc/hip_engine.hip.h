@@ -37,7 +37,7 @@ inline void hip_check(hipError_t e, const char *what) {
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][3];      // score kernels [alg][linear, symmetric linear, affine]
+    const void *kernel[2][4];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine]
     const void *fill[2];           // alignment fill kernels [alg] (linear gap model)
 };
 
@@ -46,10 +46,12 @@ constexpr Geometry make_geometry() {
     return Geometry{G, K, &wave_lds<G, K>,
                     {{(const void *)&score_kernel<G, K, kAlgSW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapSym>,
-                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>},
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>},
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
-                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>}},
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>}},
                     {(const void *)&align_fill_kernel<G, K, kAlgSW>, (const void *)&align_fill_kernel<G, K, kAlgNW>}};
 }
 
@@ -135,7 +137,11 @@ public:
         a.ext_read = (short)sc_.ext_read;
         a.open_ref = (short)sc_.open_ref;
         a.ext_ref = (short)sc_.ext_ref;
-        const int gaps = sc_.affine ? kGapAffine : (sc_.gap_read == sc_.gap_ref && !no_sym_ ? kGapSym : kGapLinear);
+        int gaps;
+        if (sc_.affine)
+            gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
+        else
+            gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
         const void *fn = plan_.geo->kernel[alg][gaps];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
