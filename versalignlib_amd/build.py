@@ -18,9 +18,10 @@ INCLUDE = os.path.join(ROOT, "include")
 
 HIP_PLUGIN = os.path.join(LIB, "libHIPKernel.so")
 HOST_LIB = os.path.join(LIB, "libvalignhost.so")
+BENCH_CLI = os.path.join(LIB, "valign-bench")
 
 HIP_SOURCES = ["hip_plugin.hip"]
-HIP_DEPS = ["hip_plugin.hip", "dp_kernels.hip.h", "hip_engine.hip.h"]
+HIP_DEPS = ["hip_plugin.hip", "dp_kernels.hip.h", "trace_kernels.hip.h", "hip_engine.hip.h"]
 HOST_SOURCES = ["valign_host.cpp"]
 
 
@@ -52,6 +53,10 @@ def build_host(force=False):
     if force or _newer(HOST_LIB, deps):
         _run(["g++", "-std=c++14", "-O2", "-fPIC", "-shared", "-Wall", "-pthread",
               "-I" + INCLUDE] + srcs + ["-o", HOST_LIB, "-ldl"])
+    cli_src = os.path.join(CSRC, "valign_bench.cpp")
+    if force or _newer(BENCH_CLI, [cli_src, HOST_LIB]):
+        _run(["g++", "-std=c++14", "-O2", "-Wall", "-I" + INCLUDE, cli_src, "-o", BENCH_CLI,
+              "-L" + LIB, "-lvalignhost", "-Wl,-rpath,$ORIGIN", "-ldl", "-pthread"])
     return HOST_LIB
 
 

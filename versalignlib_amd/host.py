@@ -192,6 +192,8 @@ def pad(seqs, fill=b"\0"):
     """pad() of the reference host: right-pad to the longest -> uint8 [n, L]."""
     if not seqs:
         return np.zeros((0, 0), dtype=np.uint8)
+    if any(b"\0" in bytes(s) for s in seqs):
+        raise ValueError("sequences are C strings for pad(): embedded NUL bytes are not representable")
     blob = b"".join(bytes(s) + b"\0" for s in seqs)
     out = ctypes.c_void_p()
     length = ctypes.c_int(0)
