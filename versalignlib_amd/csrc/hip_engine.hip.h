@@ -38,7 +38,7 @@ struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][4];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine]
-    const void *fill[2];           // alignment fill kernels [alg] (linear gap model)
+    const void *fill[2][2];        // alignment fill kernels [alg][gap_read == gap_ref] (linear gap model)
 };
 
 template <int G, int K>
@@ -52,7 +52,8 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>}},
-                    {(const void *)&align_fill_kernel<G, K, kAlgSW>, (const void *)&align_fill_kernel<G, K, kAlgNW>}};
+                    {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>},
+                     {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -220,7 +221,7 @@ public:
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
-        const void *fn = plan_.geo->fill[alg];
+        const void *fn = plan_.geo->fill[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),

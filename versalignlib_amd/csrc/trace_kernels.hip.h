@@ -53,7 +53,8 @@ __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
     return (s16x2)((u16x2)a * (u16x2)b + (u16x2)c);
 }
 
-template <int G, int K, int ALG>
+// SYM: gap_read == gap_ref, so one subtract serves both gap directions (as in score_kernel).
+template <int G, int K, int ALG, bool SYM>
 __global__ void __launch_bounds__(256)
 align_fill_kernel(const FillArgs args) {
     using geo = Geo<G, K>;
@@ -70,66 +71,114 @@ align_fill_kernel(const FillArgs args) {
 
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
     const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
-    const unsigned char *codes = w.refc + grp * args.refc_stride - 2 * l;
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
     const s16x2 one = pk(1), four = pk(4);
 
-    s16x2 Hl[K], code[K], acc[K], rb[K], fc[K];
+    // NW variant: only ONE row per pair needs its first arg-max -- the row of the last valid read
+    // base (DefaultKernel.cpp:307-315, 381-387).  sel[q] marks it per half; the owner lane tracks it.
+    int ir[2], jr[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int p_local = 2 * grp + half;
+        p_local = p_local > w.last ? w.last : p_local;
+        ir[half] = w.first_bad[2 * p_local];
+        jr[half] = w.first_bad[2 * p_local + 1];
+    }
+
+    s16x2 Hl[K], code[K], acc[K];
+    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    short nw_seed[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < K; ++q) {
+        const int p = l * K + q;
         short border = 0;
-        if (ALG == kAlgNW) {                      // column 0 of the NW variant: (i) * gap_ref, i 1-based
-            const int p = l * K + q;
+        if (ALG == kAlgNW)                         // column 0 of the NW variant: i * gap_ref, i 1-based
             border = p < pad_rows ? (short)0 : (short)((p - pad_rows + 1) * args.gap_ref);
-        }
         Hl[q] = pk(border);
-        rb[q] = pk(border);                       // row arg-max seed = the column-0 value (NW) / 0 (SW)
-        fc[q] = pk((short)l);                     // "no cell beat the seed": column index 0
         code[q] = pk(0);
         acc[q] = pk(0);
+        if (ALG == kAlgSW) {
+            rb[q] = pk(0);
+            fc[q] = pk(0);
+        } else {
+            const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
+            const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
+            sel[q] = s16x2{(short)(ta ? -1 : 0), (short)(tb ? -1 : 0)};
+            if (ta) nw_seed[0] = border;
+            if (tb) nw_seed[1] = border;
+        }
+    }
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};     // seed of the arg-max: the column-0 value of the row
+        fc[0] = pk((short)l);                      // "no cell beat the seed": column index 0
     }
     s16x2 h_last = Hl[K - 1];
     s16x2 up0 = pk(0);
+    int j = -l;
 
     const long long pp = w.pair0 / 2 + grp;       // pair-of-pairs index of this lane group
     unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
 
-    const int steps = args.blocks8 * 8;
-    for (int t = 0; t < steps; ++t) {
+    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
-        const int j = t - l;
-        if ((unsigned)j < (unsigned)F) {
-            const unsigned ca = codes[2 * t], cb = codes[2 * t + 1];
-            const unsigned addr_a = lane_base + ca * geo::kPairStride;
-            const unsigned addr_b = lane_base + cb * geo::kPairStride;
+        if (G == 16) {
+            up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
+        } else {
+            up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        }
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
             s16x2 S[K];
-            fetch_profile<G, K>(addr_a, addr_b, S);
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             const s16x2 tt = pk((short)t);
-            s16x2 dS[K], m[K];
+            s16x2 d[K], m[K];
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                dS[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
-                m[q] = pk_max(dS[q], e);
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                if (!SYM) {
+                    const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                    m[q] = pk_max(d[q], e);
+                }
             }
             s16x2 h = up0;
+            s16x2 hs = pk(0);
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const s16x2 ug = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
-                h = pk_max(m[q], ug);
+                s16x2 nu;
+                if (SYM) {
+                    // h = max(d, max(left, up) - g); it came from UP iff up >= left (priority UP > LEFT)
+                    const s16x2 x = pk_max(Hl[q], h);
+                    nu = pk_min_u(x - h, one);
+                    const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
+                    h = pk_max(d[q], y);
+                } else {
+                    const s16x2 ug = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                    h = pk_max(m[q], ug);
+                    nu = pk_min_u(h - ug, one);
+                }
                 Hl[q] = h;
-                // back pointer: 0 if h == diag + S, else 1 if h == up + gap_ref, else 2
-                const s16x2 nd = pk_min_u(h - dS[q], one);
-                const s16x2 nu = pk_min_u(h - ug, one);
+                // back pointer: 0 if h == diag + S, else 1 if it came from above, else 2
+                const s16x2 nd = pk_min_u(h - d[q], one);
                 code[q] = pk_mad_u(nd, nu, nd);
-                // per-row first arg-max (strictly greater wins, so the first column is kept)
-                const s16x2 nb = pk_max(rb[q], h);
-                const s16x2 changed = (rb[q] - nb) >> 15;         // 0xFFFF where the row best rose
-                fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
-                rb[q] = nb;
+                if (ALG == kAlgSW) {
+                    // per-row first arg-max (strictly greater wins, so the first column is kept)
+                    const s16x2 nb = pk_max(rb[q], h);
+                    const s16x2 changed = (rb[q] - nb) >> 15;     // 0xFFFF where the row best rose
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = nb;
+                } else {
+                    hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
+                }
+            }
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> 15;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
             }
             h_last = h;
         }
@@ -142,7 +191,17 @@ align_fill_kernel(const FillArgs args) {
 #pragma unroll
             for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
         }
-    }
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = args.blocks8 * 8;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t < steady_end; ++t) step(std::false_type{}, t);
+    for (; t < steps; ++t) step(std::true_type{}, t);
 
     // ---- end cell of each of the two pairs of this group ----
     const int base_lane = lane - l;
@@ -167,8 +226,8 @@ align_fill_kernel(const FillArgs args) {
             unsigned key = ((unsigned)bv << 16) | (unsigned)(0xFFFF - (l * K + bq));
             unsigned kmax = key;
 #pragma unroll
-            for (int d = G / 2; d >= 1; d >>= 1) {
-                const unsigned other = (unsigned)__shfl_xor((int)kmax, d, kWave);
+            for (int dd = G / 2; dd >= 1; dd >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)kmax, dd, kWave);
                 kmax = other > kmax ? other : kmax;
             }
             const int p = 0xFFFF - (int)(kmax & 0xFFFF);
@@ -182,21 +241,14 @@ align_fill_kernel(const FillArgs args) {
                 out.ref_pos = 0;
             }
         } else {
-            const int p_local = 2 * grp + half;
-            const int ir = w.first_bad[2 * (p_local > w.last ? w.last : p_local)];
-            const int jr = w.first_bad[2 * (p_local > w.last ? w.last : p_local) + 1];
-            const int i_end = ir - 1;                    // last valid read position (may be -1)
+            const int i_end = ir[half] - 1;               // last valid read position (may be -1)
             int arg_col = 0;
             if (i_end >= 0) {
-                const int p = i_end + pad_rows;
-                const int src_l = p / K, src_q = p % K;
-                int mine = 0;
-#pragma unroll
-                for (int q = 0; q < K; ++q)
-                    if (q == src_q) mine = ((half ? fc[q].y : fc[q].x) & 0xFFFF) - l;
+                const int src_l = (i_end + pad_rows) / K;
+                const int mine = ((half ? fc[0].y : fc[0].x) & 0xFFFF) - l;
                 arg_col = __shfl(mine, base_lane + src_l, kWave);
             }
-            const int last_ref = jr - 1;
+            const int last_ref = jr[half] - 1;
             out.score = 0;
             out.read_pos = (short)i_end;
             out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
