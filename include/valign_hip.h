@@ -82,7 +82,8 @@ int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const vo
  * [start, R+F-2], zeros before start, NUL at R+F-1 -- and d_idx = n * 4 int16
  * (readStart, readEnd, refStart, refEnd), i.e. the contents of the ABI's `Alignment`
  * (include/AlignmentKernel.h:12-18) flattened.  Tie-breaks follow the Default kernel.
- * Asynchronous on `hip_stream`; uses an internal pointer scratch (<= 3 GiB).            */
+ * Asynchronous on `hip_stream`; uses an internal pointer scratch (20.8 KB per pair at
+ * 150x500; up to 24 GiB or half the free HBM per launch, larger batches run in chunks).            */
 int valign_hip_align_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
                             const void *d_refs, void *d_rows, void *d_idx, void *hip_stream);
 

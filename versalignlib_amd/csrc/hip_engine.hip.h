@@ -216,7 +216,13 @@ public:
         const int blocks8 = (F_ + G - 1 + 7) / 8;
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
         const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4;
-        long long chunk = (long long)((3ull << 30) / bytes_per_pp) * 2;
+        // Pointer scratch: as much of the batch per launch as memory allows (a 1 M-pair launch keeps
+        // the latency-bound traceback kernel at full occupancy), capped at 24 GiB and half the free HBM.
+        size_t free_b = 0, total_b = 0;
+        hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
+        const size_t have = trace_pairs_ > 0 ? (size_t)(trace_pairs_ / 2) * bytes_per_pp : 0;
+        const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
+        long long chunk = (long long)(cap / bytes_per_pp) * 2;
         chunk = std::max(ppb, chunk / ppb * ppb);
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
@@ -285,7 +291,7 @@ public:
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const int AL = R_ + F_;
         const size_t per_pair = (size_t)3 * AL + 8;
-        long long chunk = per_pair ? (long long)((96u << 20) / per_pair) : n;
+        long long chunk = per_pair ? (long long)((256u << 20) / per_pair) : n;
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
         ensure_staging(chunk);

@@ -75,7 +75,11 @@ align_fill_kernel(const FillArgs args) {
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
-    const s16x2 one = pk(1), four = pk(4);
+    // Constants of the packed pointer / arg-max arithmetic live in VGPRs the optimiser cannot see
+    // through: otherwise min(x, 1), x * 4 and x >> 15 are rewritten into per-half compares and
+    // selects (SDWA), which costs twice the instructions of the packed forms.
+    s16x2 one = pk(1), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(four), "+v"(fifteen));
 
     // NW variant: only ONE row per pair needs its first arg-max -- the row of the last valid read
     // base (DefaultKernel.cpp:307-315, 381-387).  sel[q] marks it per half; the owner lane tracks it.
@@ -167,7 +171,7 @@ align_fill_kernel(const FillArgs args) {
                 if (ALG == kAlgSW) {
                     // per-row first arg-max (strictly greater wins, so the first column is kept)
                     const s16x2 nb = pk_max(rb[q], h);
-                    const s16x2 changed = (rb[q] - nb) >> 15;     // 0xFFFF where the row best rose
+                    const s16x2 changed = (rb[q] - nb) >> fifteen;   // 0xFFFF where the row best rose
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
                     rb[q] = nb;
                 } else {
@@ -176,7 +180,7 @@ align_fill_kernel(const FillArgs args) {
             }
             if (ALG == kAlgNW) {
                 const s16x2 nb = pk_max(rb[0], hs);
-                const s16x2 changed = (rb[0] - nb) >> 15;
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
                 fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
                 rb[0] = nb;
             }
