@@ -275,6 +275,11 @@ struct TraceArgs {
     short match, mismatch, gap_read, gap_ref;
 };
 
+typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
+
+// One lane per pair.  The walk is a chain of dependent loads, so the kernel is bound by the
+// number of memory transactions: pointer words are fetched 16 bytes (4 rows x 8 columns) at a
+// time, read/ref bases 4 at a time, and the two output rows are written as dwords.
 __global__ void __launch_bounds__(256)
 traceback_kernel(const TraceArgs a) {
     const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,10 +291,32 @@ traceback_kernel(const TraceArgs a) {
     uint8_t *row_ref = row_read + AL;
     const EndCell e = a.ends[pair];
     const unsigned *ptr_pair = a.ptr + ((pair >> 1) * G) * (long long)a.blocks8 * K;
+    const long long ptr_words = (long long)G * a.blocks8 * K;     // words of this pair-of-pairs
     const int half_shift = (int)(pair & 1) * 16;
 
     int i = e.read_pos, j = e.ref_pos, h = e.score;
     int k = AL - 2;
+    long long cached_at = -1;              // first word index held in `cache` (multiple of 4)
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int rd_at = -1, rf_at = -1;            // index / 4 of the cached read / ref dwords
+    unsigned rd_w = 0, rf_w = 0;
+    unsigned out_r = 0, out_f = 0;         // up to 4 pending output bytes per row, newest in the low byte
+    int pending = 0;
+
+    auto base_at = [](const uint8_t *seq, int len, int pos, int &at, unsigned &w) -> unsigned {
+        if ((pos >> 2) != at) {
+            at = pos >> 2;
+            const int b = at * 4;
+            if (b + 4 <= len) {
+                w = *reinterpret_cast<const u32_any_align *>(seq + b);
+            } else {
+                w = 0;
+                for (int x = 0; b + x < len; ++x) w |= (unsigned)seq[b + x] << (8 * x);
+            }
+        }
+        return (w >> (8 * (pos & 3))) & 0xFFu;
+    };
+
     while (k >= 0) {
         int move;                                   // 0 DIAG, 1 UP, 2 LEFT
         if (a.alg == kAlgSW) {
@@ -303,29 +330,55 @@ traceback_kernel(const TraceArgs a) {
             const int p = i + a.pad_rows;
             const int l = p / K, q = p - l * K;
             const int t = j + l;
-            const unsigned word = ptr_pair[((long long)l * a.blocks8 + (t >> 3)) * K + q];
+            const long long wi = ((long long)l * a.blocks8 + (t >> 3)) * K + q;
+            const long long wb = wi & ~3ll;
+            if (wb != cached_at) {
+                cached_at = wb;
+                if (wb + 4 <= ptr_words) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
+                    c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+                } else {
+                    c0 = ptr_pair[wb];
+                    c1 = wb + 1 < ptr_words ? ptr_pair[wb + 1] : 0u;
+                    c2 = wb + 2 < ptr_words ? ptr_pair[wb + 2] : 0u;
+                    c3 = 0u;
+                }
+            }
+            const int sel = (int)(wi & 3);
+            const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
             move = (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
         }
+        unsigned br, bf;
         if (move == 0) {
-            const uint8_t cr = read[i], cf = ref[j];
-            row_read[k] = cr;
-            row_ref[k] = cf;
-            const int ca = base_class(cr), cb = base_class(cf);
+            br = base_at(read, R, i, rd_at, rd_w);
+            bf = base_at(ref, F, j, rf_at, rf_w);
+            const int ca = base_class(br), cb = base_class(bf);
             if (ca >= 1 && ca <= 4 && cb >= 1 && cb <= 4) h -= (ca == cb ? a.match : a.mismatch);
             --i;
             --j;
         } else if (move == 1) {
-            row_read[k] = read[i];
-            row_ref[k] = '-';
+            br = base_at(read, R, i, rd_at, rd_w);
+            bf = '-';
             h -= a.gap_ref;
             --i;
         } else {
-            row_read[k] = '-';
-            row_ref[k] = ref[j];
+            br = '-';
+            bf = base_at(ref, F, j, rf_at, rf_w);
             h -= a.gap_read;
             --j;
         }
+        out_r = (out_r << 8) | br;
+        out_f = (out_f << 8) | bf;
+        if (++pending == 4) {                       // bytes k .. k+3 of both rows, lowest address = newest
+            *reinterpret_cast<u32_any_align *>(row_read + k) = out_r;
+            *reinterpret_cast<u32_any_align *>(row_ref + k) = out_f;
+            pending = 0;
+        }
         --k;
+    }
+    for (int x = 0; x < pending; ++x) {             // k + 1 is the newest byte written
+        row_read[k + 1 + x] = (uint8_t)(out_r >> (8 * x));
+        row_ref[k + 1 + x] = (uint8_t)(out_f >> (8 * x));
     }
     short *out = a.idx + pair * 4;
     out[0] = (short)(k + 1);
