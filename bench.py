@@ -37,6 +37,23 @@ R, F = 150, 500
 PAIRS_PER_GPU = 1 << 20
 AFFINE = dict(open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
 HBM_PEAK_GBPS = 8000.0
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r01_pmc_final.json")
+
+
+def measured_traffic(kernel_key, pairs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE in separate runs, in KB; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the profile is
+    absent or was taken at another batch size."""
+    try:
+        with open(PMC_PROFILE) as f:
+            prof = json.load(f)
+        k = prof["kernels"][kernel_key]
+        if int(prof["pairs"]) != int(pairs):
+            return None
+        return float(k["FETCH_SIZE"]) * 1024.0 * 2.0 + float(k["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def synth_on_device(n, device, seed):
@@ -205,7 +222,8 @@ def main():
                                    "inputs resident in HBM%s" % (n, ", RCCL all-gather of scores" if world > 1 else ""),
                        "pairs_per_gpu": n, "read_length": R, "ref_length": F, "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                         "traffic": measured_traffic("score_kernel<%d, %d, 0, 3>" % (d["group_lanes"], d["rows_per_lane"]), n),
                          "kernel": "score_kernel<%d,%d,SW,affine>" % (d["group_lanes"], d["rows_per_lane"]),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
                          "kernel_gcups": round(n * R * F / (k_ms * 1e-3) / 1e9, 1),

@@ -14,5 +14,7 @@ for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             continue
         short = name.split("(")[0].replace("void valign::", "")
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+out = {"pairs": pairs, "units": "mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them",
+       "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in acc.items()}}
 print(json.dumps(out, indent=1))
