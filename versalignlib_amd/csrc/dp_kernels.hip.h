@@ -39,6 +39,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
+constexpr int kWaveLanes = 64;
 constexpr int kAlgSW = 0;
 constexpr int kAlgNW = 1;
 constexpr short kNegInf = -16384;   // "minus infinity" of the affine NW borders (oracle: NEG_INF)
@@ -85,6 +86,41 @@ __device__ __forceinline__ int base_class(unsigned ch) {
     return c;
 }
 
+// LDS bank conflicts of one profile fetch, modelled per MI355X_MICROARCH.md section LDS: every lane of
+// a group of G reads `lane_dw` dwords at dword address slab(pair of its group) * stride + l * lane_dw.
+// width = dwords per load instruction (1: ds_read_b32 / read2_b32, banks mod 32, lane groups of 32;
+// 2: ds_read_b64, banks mod 64, groups of 32; 4: ds_read_b128, banks mod 64, four fixed groups of 16).
+// Returns the number of extra LDS cycles when every lane selects the same class (the systematic case).
+constexpr int profile_conflicts(int G, int lane_dw, int width, int stride_dw) {
+    const int banks = width == 1 ? 32 : 64;
+    int extra = 0;
+    const int ngroups = width == 4 ? 4 : 2;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        int hits[64] = {};
+        int worst = 0;
+        for (int lane = 0; lane < kWaveLanes; ++lane) {
+            int member = 0;
+            if (width == 4) {
+                const int m = lane & 31;                       // {0-3,12-15,20-27} vs the rest, per half
+                const bool first = m < 4 || (m >= 12 && m < 16) || (m >= 20 && m < 28);
+                member = (lane < 32 ? 0 : 2) + (first ? 0 : 1);
+            } else {
+                member = lane / 32;
+            }
+            if (member != grp) continue;
+            const int l = lane % G, pair = 2 * (lane / G);
+            const int dw = pair * stride_dw + l * lane_dw;
+            for (int x = 0; x < width; ++x) {
+                const int b = (dw + x) % banks;
+                hits[b] += 1;
+                worst = hits[b] > worst ? hits[b] : worst;
+            }
+        }
+        extra += worst - 1;
+    }
+    return extra;
+}
+
 // Geometry of one kernel instantiation.
 template <int G, int K>
 struct Geo {
@@ -94,7 +130,23 @@ struct Geo {
     static constexpr int kPairs = 2 * kGroups;       // pairs per wave
     static constexpr int kRows = G * K;              // padded rows
     static constexpr int kLaneBytes = K * 2;         // one lane's K int16 scores, contiguous
-    static constexpr int kPairStride = kRows * 2;    // bytes of one (class, pair) array
+    static constexpr int kLoadDwords = (K * 2) % 16 == 0 ? 4 : ((K * 2) % 8 == 0 ? 2 : 1);
+    // Slab stride: the rows plus the padding (in units of one load) that minimises the systematic
+    // bank conflicts between the lane groups of a wave (e.g. 16x10: 80 -> 88 dwords turns an
+    // always-2-way conflict between groups 0/1 and 2/3 into none).
+    static constexpr int slab_dwords() {
+        const int rows_dw = kRows / 2;
+        int best = rows_dw, best_cost = profile_conflicts(G, K / 2, kLoadDwords, rows_dw);
+        for (int pad = kLoadDwords; pad < 64 && best_cost > 0; pad += kLoadDwords) {
+            const int c = profile_conflicts(G, K / 2, kLoadDwords, rows_dw + pad);
+            if (c < best_cost) {
+                best_cost = c;
+                best = rows_dw + pad;
+            }
+        }
+        return best;
+    }
+    static constexpr int kPairStride = slab_dwords() * 4;   // bytes of one (class, pair) slab
     // profile slabs: slab (class * kPairs + pair) for classes 0..3, plus ONE all-zero slab
     // shared by every pair for "this reference base scores nothing"
     static constexpr int kZeroSlab = 4 * kPairs;
