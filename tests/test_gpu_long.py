@@ -1,0 +1,56 @@
+"""Long-read score path (row strips + column phases, BASELINE config 5 shape): same results
+as the oracle, SW and NW variant, including shapes that would also fit the resident kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from versalignlib_amd import build, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def forced_long(monkeypatch):
+    monkeypatch.setenv("VALIGN_HIP_FORCE_LONG", "1")
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 1), (160, 64, 50, 2), (161, 700, 33, 3),
+                                         (400, 333, 40, 4), (12, 20, 100, 5), (1000, 1300, 17, 6)])
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_forced_long_path_matches_oracle(forced_long, R, F, n, seed, gaps):
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08,
+                                   lowercase_frac=0.05, junk_frac=0.05)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1]) as hip:
+        assert '"long_mode": 1' in (hip.score_alignments(0, reads[:1], refs[:1]) is not None and hip.drain_log())
+        for opt in (0, 1):
+            got = hip.score_alignments(opt, reads, refs)
+            exp = cpu_ref.score(opt, reads, refs, sc, threads=8)
+            assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8], got[:8], exp[:8])
+
+
+@pytest.mark.parametrize("R,F,n", [(3000, 3500, 12), (2500, 700, 9)])
+def test_long_shapes_select_the_long_path(R, F, n):
+    reads, refs = synth.make_pairs(n, R, F, seed=R, indel_rate=0.01, n_run_frac=0.1, short_frac=0.1)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        for opt in (0, 1):
+            got = hip.score_alignments(opt, reads, refs)
+            assert np.array_equal(got, cpu_ref.score(opt, reads, refs, threads=8))
+        assert '"long_mode": 1' in hip.drain_log()
+        with pytest.raises(host.PluginError, match="one register sweep"):
+            hip.compute_alignments(0, reads, refs)
+
+
+def test_config5_shape_10k_by_10k():
+    """BASELINE config 5 at a size the oracle finishes in seconds: unbanded, int16 (SW cells of a
+    10 kbp x 10 kbp pair stay below 20000)."""
+    R = F = 10000
+    n = 5
+    reads, refs = synth.make_pairs(n, R, F, seed=55, sub_rate=0.1, indel_rate=0.0, n_run_frac=0.2, short_frac=0.2)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    exp = cpu_ref.score(0, reads, refs, threads=8)
+    assert np.array_equal(got, exp), (got, exp)
+    assert exp.max() > 10000          # the batch does exercise large cell values

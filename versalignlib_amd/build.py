@@ -21,7 +21,7 @@ HOST_LIB = os.path.join(LIB, "libvalignhost.so")
 BENCH_CLI = os.path.join(LIB, "valign-bench")
 
 HIP_SOURCES = ["hip_plugin.hip"]
-HIP_DEPS = ["hip_plugin.hip", "dp_kernels.hip.h", "trace_kernels.hip.h", "hip_engine.hip.h"]
+HIP_DEPS = ["hip_plugin.hip", "dp_kernels.hip.h", "trace_kernels.hip.h", "long_kernels.hip.h", "hip_engine.hip.h"]
 HOST_SOURCES = ["valign_host.cpp"]
 
 

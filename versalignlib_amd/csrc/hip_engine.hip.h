@@ -19,6 +19,7 @@
 
 #include "dp_kernels.hip.h"
 #include "trace_kernels.hip.h"
+#include "long_kernels.hip.h"
 
 namespace valign {
 
@@ -69,7 +70,14 @@ constexpr int kNumGeometries = sizeof(kGeometries) / sizeof(kGeometries[0]);
 constexpr int kMaxBlockLds = 160 * 1024;       // gfx950: 160 KiB per CU, one block may take it all
 constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribute must be raised
 
+// Long-read path (row strips + column phases, long_kernels.hip.h): one geometry, linear gaps.
+constexpr int kLongG = 16, kLongK = 10;
+static const void *const kLongKernels[2][2] = {
+    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true>},
+    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true>}};
+
 struct LaunchPlan {
+    bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
     const Geometry *geo = nullptr;
     WaveLds lds{};
     int waves_per_block = 4;
@@ -104,6 +112,7 @@ public:
         (void)hipSetDevice(device_);
         release_staging();
         release_trace_scratch();
+        if (d_brow_) (void)hipFree(d_brow_);
         for (int s = 0; s < 2; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
             if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
@@ -120,6 +129,11 @@ public:
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;          // reference: unsupported mode is a silent no-op
         hip_check(hipSetDevice(device_), "hipSetDevice");
+        check_int16_range(alg);
+        if (plan_.long_mode) {
+            score_long_device(alg, n, d_reads, d_refs, d_scores, stream);
+            return;
+        }
         ScoreArgs a;
         a.reads = d_reads;
         a.refs = d_refs;
@@ -155,6 +169,63 @@ public:
         hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), kargs,
                                   (size_t)block_lds, stream),
                   "hipLaunchKernel(score_kernel)");
+    }
+
+
+    // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
+    void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
+                           hipStream_t stream) {
+        if (sc_.affine)
+            throw std::runtime_error("the long-read path implements the linear gap model only (read_length " +
+                                     std::to_string(R_) + " needs row strips)");
+        const int rows = kLongG * kLongK;
+        const int ppw = plan_.pairs_per_wave;
+        LongArgs a;
+        a.R = R_;
+        a.F = F_;
+        a.strips = std::max(1, (R_ + rows - 1) / rows);
+        a.row_dwords = ((F_ + kLongG + kPhase - 1) / kPhase) * kPhase + kPhase;
+        a.match = (short)sc_.match;
+        a.mismatch = (short)sc_.mismatch;
+        a.gap_read = (short)sc_.gap_read;
+        a.gap_ref = (short)sc_.gap_ref;
+        const size_t bytes_per_wave = (size_t)2 * (ppw / 2) * a.row_dwords * 4;
+        long long chunk = (long long)((8ull << 30) / bytes_per_wave) * ppw;
+        chunk = std::max<long long>(ppw, std::min(chunk, (n + ppw - 1) / ppw * ppw));
+        const long long waves = chunk / ppw;
+        if ((size_t)waves * bytes_per_wave > brow_bytes_) {
+            hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if (d_brow_) (void)hipFree(d_brow_);
+            d_brow_ = nullptr;
+            brow_bytes_ = (size_t)waves * bytes_per_wave;
+            hip_check(hipMalloc((void **)&d_brow_, brow_bytes_), "hipMalloc(boundary rows)");
+        }
+        const void *fn = kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0];
+        for (long long begin = 0; begin < n; begin += chunk) {
+            const long long cnt = std::min(chunk, n - begin);
+            a.reads = d_reads + (size_t)begin * R_;
+            a.refs = d_refs + (size_t)begin * F_;
+            a.scores = d_scores + begin;
+            a.brow = d_brow_;
+            a.n = cnt;
+            a.pp_total = waves * (ppw / 2);
+            void *kargs[] = {&a};
+            hip_check(hipLaunchKernel(fn, dim3((unsigned)((cnt + ppw - 1) / ppw)), dim3(kWave), kargs,
+                                      (size_t)plan_.lds.total, stream),
+                      "hipLaunchKernel(score_long_kernel)");
+        }
+    }
+
+    // int16 DP cells: the reference wraps silently; refuse (shape, scoring, mode) where it could.
+    void check_int16_range(int alg) const {
+        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        const int worst_gap = std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, 0});
+        // SW cells are >= 0; NW-variant score cells are bounded below by the cheaper border path
+        const long long lo = alg == kAlgSW ? (long long)std::min(sc_.mismatch, 0) + worst_gap
+                                           : (long long)(std::min(R_, F_) + 2) * std::min(worst_gap, std::min(sc_.mismatch, 0));
+        if (hi > 32000 || lo < -32000 || (sc_.affine && alg == kAlgNW && lo < -15000))
+            throw std::runtime_error("shape x scoring can leave the int16 range of the DP cells (read_length " +
+                                     std::to_string(R_) + ", ref_length " + std::to_string(F_) + ")");
     }
 
     // Host pointers in, host scores out.  Chunked: while chunk c runs on the device the
@@ -211,6 +282,12 @@ public:
         if (sc_.affine)
             throw std::runtime_error("compute_alignments implements the reference's linear gap model only; "
                                      "unset the score_gap_open_*/extend_* keys");
+        if (plan_.long_mode)
+            throw std::runtime_error("compute_alignments needs the pair to fit one register sweep (read_length <= 2048, "
+                                     "reference resident in LDS); this shape only supports score_alignments");
+        check_int16_range(alg);
+        if (alg == kAlgNW && (long long)(R_ + 1) * std::min(sc_.gap_ref, 0) < -32000)
+            throw std::runtime_error("NW alignment border (read_length * score_gap_ref) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
         const int blocks8 = (F_ + G - 1 + 7) / 8;
@@ -327,14 +404,15 @@ public:
 
     std::string describe(int opt, long long n) const {
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        char buf[512];
+        char buf[640];
         snprintf(buf, sizeof buf,
                  "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
-                 "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld}",
+                 "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
-                 plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0);
+                 plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
+                 plan_.long_mode ? 1 : 0);
         return buf;
     }
 
@@ -348,12 +426,6 @@ private:
         const bool gaps_ok = sc_.affine ? (sc_.open_read <= 0 && sc_.ext_read <= 0 && sc_.open_ref <= 0 && sc_.ext_ref <= 0)
                                         : (sc_.gap_read <= 0 && sc_.gap_ref <= 0);
         if (!gaps_ok) throw std::runtime_error("positive gap scores are not supported by the HIP kernels");
-        // int16 DP: the reference wraps silently; refuse shapes where it could.
-        const long long lo = (long long)(R_ + F_ + 2) * std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref,
-                                                                  sc_.ext_read, sc_.ext_ref, sc_.mismatch, 0});
-        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
-        if (hi > 32000 || lo < -16000)
-            throw std::runtime_error("shape x scoring can leave the int16 range of the DP cells");
     }
 
     LaunchPlan choose_plan(int force_g, int force_k) const {
@@ -401,9 +473,19 @@ private:
                 best_cost = cost;
             }
         }
-        if (!best.geo)
-            throw std::runtime_error("no kernel geometry fits read_length=" + std::to_string(R_) + ", ref_length=" +
-                                     std::to_string(F_) + " (rows <= 2048 and LDS <= 160 KiB per block are supported)");
+        if (!best.geo || (getenv("VALIGN_HIP_FORCE_LONG") && !force_g)) {
+            if (force_g || force_k)
+                throw std::runtime_error("the forced kernel geometry does not fit read_length=" + std::to_string(R_) +
+                                         ", ref_length=" + std::to_string(F_));
+            LaunchPlan p;                  // row strips + column phases: any length the ABI allows
+            p.long_mode = true;
+            p.pairs_per_wave = 2 * (kWave / kLongG);
+            p.waves_per_block = 1;
+            p.lds.total = LongLds<kLongG, kLongK>::kTotal;
+            for (int i = 0; i < kNumGeometries; ++i)
+                if (kGeometries[i].G == kLongG && kGeometries[i].K == kLongK) p.geo = &kGeometries[i];
+            return p;
+        }
         return best;
     }
 
@@ -552,6 +634,8 @@ private:
     uint8_t *d_reads_[2] = {nullptr, nullptr}, *d_refs_[2] = {nullptr, nullptr};
     int16_t *d_scores_[2] = {nullptr, nullptr};
     // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
+    unsigned *d_brow_ = nullptr;       // long-read path: strip boundary rows
+    size_t brow_bytes_ = 0;
     unsigned *d_ptr_ = nullptr;
     EndCell *d_ends_ = nullptr;
     long long trace_pairs_ = 0, align_staged_pairs_ = 0;

@@ -1,0 +1,235 @@
+// long_kernels.hip.h -- score kernel for sequences that do not fit one register sweep
+// (BASELINE config 5: 10 kbp x 10 kbp).  Same recurrences and results as score_kernel
+// (reference semantics: src/Kernels/default/DefaultKernel.cpp:83-202), different staging:
+//
+//   * ROW STRIPS.  The read is cut into strips of G*K rows (160 for the 16x10 geometry).  A lane
+//     group sweeps one strip over the whole reference, then the next; the bottom row of a strip
+//     (one packed dword per column and pair-of-pairs) goes to an HBM row buffer and comes back
+//     as the "row above" of the next strip.  Padding rows sit above strip 0, as in score_kernel.
+//   * COLUMN PHASES.  Nothing of length F lives in LDS: every kPhase (64) steps the wave refills
+//     three small LDS rings -- the next 64 reference class codes of its 8 pairs, the next 64
+//     boundary values coming in, and it drains the 64 boundary values going out -- all with
+//     coalesced 16-byte accesses.  LDS per wave is ~17 KB whatever R and F are.
+//   * The query profile is rebuilt per strip (2K byte loads per lane).
+//
+// Traffic per pair: F bytes of reference per strip + 8 bytes per column and strip of boundary
+// rows; at 10k x 10k that is 0.007 B per cell -- this path stays VALU bound as well.
+#pragma once
+
+#include "dp_kernels.hip.h"
+
+namespace valign {
+
+constexpr int kPhase = 64;                 // steps between ring refills; must be >= G - 1
+constexpr int kRing = 2 * kPhase;          // ring slots per lane group
+
+struct LongArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    int16_t *scores;
+    unsigned *brow;            // [2][pair-of-pairs][row_dwords] boundary rows (double buffered by strip)
+    long long n;
+    long long pp_total;        // pair-of-pairs slots in brow
+    int R, F;
+    int strips;                // ceil(R / (G*K))
+    int row_dwords;            // dwords per boundary row: F rounded up to kPhase, plus kPhase
+    short match, mismatch;
+    short gap_read, gap_ref;
+};
+
+template <int G, int K>
+struct LongLds {
+    using geo = Geo<G, K>;
+    static constexpr int kCodes = geo::kProfBytes;                        // [groups][kRing][2] bytes
+    static constexpr int kIn = kCodes + geo::kGroups * kRing * 2;         // [groups][kRing] dwords
+    static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
+    static constexpr int kTotal = kOut + geo::kGroups * kRing * 4;
+};
+
+template <int G, int K, int ALG, bool SYM>
+__global__ void __launch_bounds__(64)
+score_long_kernel(const LongArgs args) {
+    using geo = Geo<G, K>;
+    using lay = LongLds<G, K>;
+    static_assert(kPhase >= G - 1, "a phase must cover the pipeline skew");
+    const int lane = threadIdx.x;
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R, F = args.F;
+    const long long pair0 = (long long)blockIdx.x * geo::kPairs;
+    if (pair0 >= args.n) return;                                          // one wave per block
+    const int last = (int)((args.n - pair0 < geo::kPairs ? args.n - pair0 : geo::kPairs) - 1);
+    const int pad_rows = args.strips * geo::kRows - R;
+
+    unsigned char *prof = valign_smem;
+    unsigned char *codes = valign_smem + lay::kCodes;
+    unsigned *ring_in = reinterpret_cast<unsigned *>(valign_smem + lay::kIn);
+    unsigned *ring_out = reinterpret_cast<unsigned *>(valign_smem + lay::kOut);
+
+    const unsigned lane_base = lds_offset(prof) + l * geo::kLaneBytes;
+    const unsigned codes_base = lds_offset(codes) + grp * (kRing * 2);
+    const unsigned in_base = lds_offset(ring_in) + grp * (kRing * 4);
+    unsigned *out_grp = ring_out + grp * kRing;
+    const long long pp0 = pair0 / 2;                                      // first pair-of-pairs of the wave
+
+    const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
+    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
+
+    s16x2 best = pk(0), col_best = pk(0), row_best = pk(0);
+    const int steps = F + G - 1;
+
+    for (int i = lane; i < geo::kPairStride / 4; i += kWave)
+        reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
+
+    for (int s = 0; s < args.strips; ++s) {
+        // ---- query profile of this strip's rows ----
+        __syncthreads();                       // the previous strip is done with the profile
+#pragma unroll
+        for (int i = 0; i < 2 * K; ++i) {
+            const int idx = lane + kWave * i;
+            const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
+            const int ps = p > last ? last : p;
+            const int grow = s * geo::kRows + rr - pad_rows;              // read position of this row
+            const int a = (grow >= 0 && grow < R) ? base_class(args.reads[(pair0 + ps) * R + grow]) : 0;
+            const bool valid = a >= 1 && a <= 4;
+            const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const short sc = valid ? (a == c + 1 ? args.match : args.mismatch) : (short)0;
+                *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
+            }
+        }
+        const unsigned *brow_prev = args.brow + (long long)((s & 1) ^ 1) * args.pp_total * args.row_dwords;
+        unsigned *brow_cur = args.brow + (long long)(s & 1) * args.pp_total * args.row_dwords;
+
+        s16x2 Hl[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) Hl[q] = pk(0);
+        s16x2 up0 = pk(0), h_last = pk(0);
+        int j = -l;
+
+        auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const s16x2 diag0 = up0;
+            // row above: previous lane of the group; for the first lane the previous strip's bottom row
+            const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x138, 0xF, 0xF, true);
+            const unsigned from_ring = *(lds_cu32 *)(in_base + ((t & (kRing - 1)) << 2));
+            up0 = as_pk(l == 0 ? from_ring : from_lane);
+            if (!MASKED || (unsigned)j < (unsigned)F) {
+                const unsigned ca_addr = codes_base + ((j & (kRing - 1)) << 1);
+                const unsigned ca = *(lds_cu8 *)(ca_addr), cb = *(lds_cu8 *)(ca_addr + 1);
+                s16x2 S[K];
+                fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+                s16x2 d[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                    if (ALG == kAlgSW) best = pk_max(best, d[q]);
+                }
+                s16x2 h = up0;
+                if (SYM) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        const s16x2 x = pk_max(Hl[q], h);
+                        const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
+                        h = pk_max(d[q], y);
+                        Hl[q] = h;
+                    }
+                } else {
+                    s16x2 m[K];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                        m[q] = pk_max(d[q], e);
+                    }
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        const s16x2 f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                        h = pk_max(m[q], f);
+                        Hl[q] = h;
+                    }
+                }
+                h_last = h;
+                if (l == G - 1) {
+                    out_grp[j & (kRing - 1)] = as_u32(h);                  // bottom row of the strip
+                    if (ALG == kAlgNW) row_best = pk_max(row_best, h);
+                }
+            }
+            ++j;
+        };
+
+        for (int t0 = 0; t0 < steps; t0 += kPhase) {
+            // ---- ring refill for columns [t0, t0 + kPhase) ----
+            {
+                // class codes: lane -> pair lane/8, eight columns
+                const int p = lane / 8, c0 = t0 + (lane % 8) * 8;
+                const int ps = p > last ? last : p;
+                const uint8_t *src = args.refs + (pair0 + ps) * F;
+                unsigned char *dst = codes + (p / 2) * (kRing * 2) + (p & 1);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int col = c0 + x;
+                    const int c = col < F ? base_class(src[col]) : 0;
+                    dst[(col & (kRing - 1)) * 2] =
+                        (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+                }
+                // boundary values: lane -> group lane/16, four columns
+                const int g = lane / 16, col = t0 + (lane % 16) * 4;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (s > 0) {       // L2-served load: the same addresses were read two strips ago and rewritten since
+                    const u32x4 raw = __builtin_nontemporal_load(
+                        reinterpret_cast<const u32x4 *>(brow_prev + (pp0 + g) * args.row_dwords + col));
+                    v = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                }
+                *reinterpret_cast<uint4 *>(ring_in + g * kRing + (col & (kRing - 1))) = v;
+                if (t0 >= 2 * kPhase && s + 1 < args.strips) {           // drain what lane G-1 finished two phases ago
+                    const int oc = col - 2 * kPhase;
+                    *reinterpret_cast<uint4 *>(brow_cur + (pp0 + g) * args.row_dwords + oc) =
+                        *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
+                }
+            }
+            __syncthreads();
+            const int t1 = t0 + kPhase < steps ? t0 + kPhase : steps;
+            if (t0 >= G - 1 && t1 <= F) {
+                for (int t = t0; t < t1; ++t) step(std::false_type{}, t);
+            } else {
+                for (int t = t0; t < t1; ++t) step(std::true_type{}, t);
+            }
+        }
+        // ---- drain the last two phases of the outgoing row ----
+        __syncthreads();
+        if (s + 1 < args.strips) {
+            const int phases = (steps + kPhase - 1) / kPhase;
+            const int g = lane / 16;
+            for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
+                const int oc = ph * kPhase + (lane % 16) * 4;
+                if (oc + 4 <= args.row_dwords)
+                    *reinterpret_cast<uint4 *>(brow_cur + (pp0 + g) * args.row_dwords + oc) =
+                        *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
+            }
+        }
+        if (ALG == kAlgNW) {                    // every lane froze at the last column: this strip's rows
+#pragma unroll
+            for (int q = 0; q < K; ++q) col_best = pk_max(col_best, Hl[q]);
+            if (s + 1 < args.strips) row_best = pk(0);     // only the last strip holds the last row
+        }
+    }
+
+    s16x2 res;
+    if (ALG == kAlgSW) {
+        res = best;
+    } else {
+        res = pk_max(col_best, l == G - 1 ? row_best : pk(0));
+        res = pk_max(res, pk(0));
+    }
+#pragma unroll
+    for (int dd = G / 2; dd >= 1; dd >>= 1)
+        res = pk_max(res, as_pk((unsigned)__shfl_xor((int)as_u32(res), dd, kWave)));
+    if (l == 0) {
+        const long long pa = pair0 + 2 * grp;
+        if (pa < args.n) args.scores[pa] = res.x;
+        if (pa + 1 < args.n) args.scores[pa + 1] = res.y;
+    }
+}
+
+}  // namespace valign
