@@ -16,7 +16,7 @@
  *     (DefaultKernel.h:70-75); a missing one makes spawn throw the same C string.
  *     Optional keys, probed with has_key (a reference host simply lacks them):
  *       score_gap_open_read / score_gap_extend_read /
- *       score_gap_open_ref  / score_gap_extend_ref ... affine-gap extension (all four)
+ *       score_gap_open_ref  / score_gap_extend_ref ... affine-gap extension (scores and alignments)
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
@@ -77,7 +77,8 @@ void valign_hip_engine_destroy(valign_hip_engine *e);
 int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
                             const void *d_refs, void *d_scores, void *hip_stream);
 
-/* Align n device-resident pairs (reference linear gap model): d_rows = n * 2 * (R+F) bytes,
+/* Align n device-resident pairs (linear gaps: the reference's model, Default-kernel tie-breaks;
+ * affine scoring: the Gotoh extension, same tie-breaks where they apply): d_rows = n * 2 * (R+F) bytes,
  * per pair the read row then the ref row -- right-justified gapped strings in
  * [start, R+F-2], zeros before start, NUL at R+F-1 -- and d_idx = n * 4 int16
  * (readStart, readEnd, refStart, refEnd), i.e. the contents of the ABI's `Alignment`

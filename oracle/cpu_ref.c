@@ -324,6 +324,133 @@ int vref_score_affine(int opt, int n, int R, int F, const uint8_t *reads, const 
     return n;
 }
 
+
+/* ---- affine-gap alignments (extension, no reference counterpart) ----
+ * Three-state Gotoh traceback whose tie-breaks are chosen so that open == extend == g walks
+ * exactly the path of the linear model above (the only reference-pinned case):
+ *   at H(i,j):  START if H == 0 (SW)  >  DIAG if H == H(i-1,j-1)+S  >  F (gap in the ref, UP)  >  E (LEFT)
+ *   at F(i,j):  emit (read[i], '-'); it was OPENED from H(i-1,j) if F == H(i-1,j)+open_ref (preferred
+ *               on ties), else extended from F(i-1,j)
+ *   at E(i,j):  emit ('-', ref[j]); opened from H(i,j-1) if E == H(i,j-1)+open_read (preferred), else
+ *               extended from E(i,j-1)
+ * Borders: SW all 0; NW variant H(0,j) = 0 (START), H(i,0) = open_ref + (i-1)*ext_ref (UP all the
+ * way), E(i,0) = F(0,j) = NEG_INF.  End cells as in the linear model.                              */
+typedef struct {
+    uint8_t h;      /* 0 START, 1 DIAG, 2 UP (came from F), 3 LEFT (came from E) */
+    uint8_t f_ext;  /* F(i,j) extended F(i-1,j) (1) or opened from H(i-1,j) (0)   */
+    uint8_t e_ext;  /* E(i,j) extended E(i,j-1) (1) or opened from H(i,j-1) (0)   */
+} aff_ptr;
+
+static void affine_fill(int alg, const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                        const vref_scoring *sc, int16_t *Hrow, int16_t *Frow, aff_ptr *ptr, int *end_i, int *end_j) {
+    const int16_t oR = (int16_t)sc->open_read, eR = (int16_t)sc->ext_read;
+    const int16_t oF = (int16_t)sc->open_ref, eF = (int16_t)sc->ext_ref;
+    for (int j = 0; j <= F; ++j) { Hrow[j] = 0; Frow[j] = NEG_INF; }
+    int16_t best = 0; int bi = 0, bj = 0;
+    int16_t last_read = (int16_t)(R - 1), last_ref = (int16_t)(F - 1);
+    int16_t row_best = INT16_MIN, row_arg = 0, snap_arg = -1;
+    for (int i = 0; i < R; ++i) {
+        const int16_t *srow = tab[g_class[read[i]]];
+        aff_ptr *prow = ptr + (size_t)(i + 1) * (F + 1);
+        int16_t hdiag = Hrow[0];
+        int16_t hleft = 0;
+        if (alg == 1) {
+            hleft = (int16_t)(oF + i * eF);                 /* H(i+1, 0) */
+            prow[0].h = 2; prow[0].f_ext = (uint8_t)(i > 0); prow[0].e_ext = 0;
+            if (last_read == R - 1 && g_class[read[i]] == 0) last_read = (int16_t)(i - 1);
+            if (last_read + 1 == i) snap_arg = row_arg;
+            row_best = hleft; row_arg = 0;
+        }
+        const int16_t hcol0 = hleft;
+        int16_t e = NEG_INF;
+        for (int j = 0; j < F; ++j) {
+            const int16_t hup = Hrow[j + 1];
+            const int16_t e_open = sat_add(hleft, oR), e_extd = sat_add(e, eR);
+            const int16_t f_open = sat_add(hup, oF), f_extd = sat_add(Frow[j + 1], eF);
+            e = max16(e_extd, e_open);
+            const int16_t f = max16(f_extd, f_open);
+            const int16_t diag = (int16_t)(hdiag + srow[g_class[ref[j]]]);
+            int16_t h = max16(max16(diag, e), f);
+            if (alg == 0) h = max16(h, 0);
+            aff_ptr p;
+            p.f_ext = (uint8_t)(f != f_open);
+            p.e_ext = (uint8_t)(e != e_open);
+            if (alg == 0 && h == 0) p.h = 0;
+            else if (h == diag) p.h = 1;
+            else if (h == f) p.h = 2;
+            else p.h = 3;
+            prow[j + 1] = p;
+            if (alg == 0) {
+                if (h > best) { best = h; bi = i; bj = j; }
+            } else {
+                if (last_ref == F - 1 && g_class[ref[j]] == 0) last_ref = (int16_t)(j - 1);
+                if (h > row_best) { row_best = h; row_arg = (int16_t)j; }
+            }
+            Frow[j + 1] = f;
+            hdiag = hup;
+            Hrow[j + 1] = h;
+            hleft = h;
+        }
+        Hrow[0] = hcol0;
+    }
+    if (alg == 0) { *end_i = bi; *end_j = bj; }
+    else {
+        if (snap_arg < 0) snap_arg = row_arg;
+        *end_i = last_read;
+        *end_j = last_ref < snap_arg ? last_ref : snap_arg;
+    }
+}
+
+int vref_align_affine(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                      const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int alg = opt & 0xF, AL = R + F;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t *Hrow = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
+        int16_t *Frow = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
+        aff_ptr *ptr = (aff_ptr *)malloc(sizeof(aff_ptr) * (size_t)(R + 1) * (F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(ptr, 0, sizeof(aff_ptr) * (size_t)(R + 1) * (F + 1));      /* row 0: START */
+            int rp, fp;
+            affine_fill(alg, rd, rf, R, F, tab, sc, Hrow, Frow, ptr, &rp, &fp);
+            uint8_t *row_read = rows_out + (size_t)p * 2 * AL, *row_ref = row_read + AL;
+            memset(row_read, 0, (size_t)AL);
+            memset(row_ref, 0, (size_t)AL);
+            int k = AL - 2, state = 0;                      /* 0 at H, 2 inside F, 3 inside E */
+            for (;;) {
+                const aff_ptr q = ptr[(size_t)(rp + 1) * (F + 1) + fp + 1];
+                if (state == 0) {
+                    if (q.h == 0) break;
+                    if (q.h == 1) { row_read[k] = rd[rp--]; row_ref[k] = rf[fp--]; --k; }
+                    else state = q.h;                       /* enter the gap state, nothing emitted yet */
+                } else if (state == 2) {
+                    row_read[k] = rd[rp]; row_ref[k] = '-'; --k;
+                    state = q.f_ext ? 2 : 0;
+                    --rp;
+                } else {
+                    row_read[k] = '-'; row_ref[k] = rf[fp]; --k;
+                    state = q.e_ext ? 3 : 0;
+                    --fp;
+                }
+            }
+            int16_t *idx = idx_out + (size_t)p * 4;
+            idx[0] = (int16_t)(k + 1); idx[1] = (int16_t)(AL - 1);
+            idx[2] = (int16_t)(k + 1); idx[3] = (int16_t)(AL - 1);
+        }
+        free(ptr);
+        free(Frow);
+        free(Hrow);
+    }
+    return n;
+}
+
 int vref_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

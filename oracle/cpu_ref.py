@@ -58,8 +58,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, i16p, ctypes.c_int]
-        L.vref_align.restype = ctypes.c_int
-        L.vref_align.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, u8p, i16p, ctypes.c_int]
+        for name in ("vref_align", "vref_align_affine"):
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, u8p, i16p, ctypes.c_int]
         L.vref_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -89,7 +91,7 @@ def score(opt, reads, refs, scoring=None, threads=1, affine=False):
     return out
 
 
-def align(opt, reads, refs, scoring=None, threads=1):
+def align(opt, reads, refs, scoring=None, threads=1, affine=False):
     """-> rows uint8 [n,2,R+F] (zero before start, NUL at R+F-1), idx int16 [n,4]."""
     reads, refs = _check(reads, refs)
     sc = scoring or Scoring.make()
@@ -97,8 +99,9 @@ def align(opt, reads, refs, scoring=None, threads=1):
     F = refs.shape[1]
     rows = np.zeros((n, 2, R + F), dtype=np.uint8)
     idx = np.zeros((n, 4), dtype=np.int16)
-    lib().vref_align(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), _u8(rows),
-                     idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
+    fn = lib().vref_align_affine if affine else lib().vref_align
+    fn(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), _u8(rows),
+       idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
     return rows, idx
 
 

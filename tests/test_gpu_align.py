@@ -116,10 +116,56 @@ def test_align_device_entry_point_and_roundtrip_property():
     eng.close()
 
 
-def test_affine_alignments_are_refused_loudly():
-    R, F = 20, 30
-    reads, refs = _data(R, F, 4, 5)
-    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_open_read=-5, score_gap_extend_read=-1,
-                     score_gap_open_ref=-5, score_gap_extend_ref=-1) as hip:
-        with pytest.raises(host.PluginError, match="linear gap model"):
-            hip.compute_alignments(0, reads, refs)
+@pytest.mark.parametrize("R,F,n,seed", [(64, 128, 300, 31), (150, 500, 257, 32), (33, 70, 200, 33), (100, 37, 90, 34)])
+@pytest.mark.parametrize("aff", [(-5, -1, -5, -1), (-3, -3, -3, -3), (-6, -2, -4, -1), (-2, -2, -4, -4)])
+def test_affine_alignments(R, F, n, seed, aff):
+    """BASELINE config 3 (NW affine + traceback) and its SW twin.  The affine model is an extension
+    (parity unpinned by the reference): checked against the repo's Gotoh oracle, and for
+    open == extend against the LINEAR oracle, i.e. the reference Default kernel's tie-breaks."""
+    reads, refs = _data(R, F, n, seed)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1],
+                score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            _assert_same(got, cpu_ref.align(opt, reads, refs, sc, threads=8, affine=True), (aff, opt))
+            if aff[0] == aff[1] and aff[2] == aff[3]:
+                lin = cpu_ref.Scoring.make(2, -1, aff[0], aff[2])
+                _assert_same(got, cpu_ref.align(opt, reads, refs, lin, threads=8), ("degenerate", aff, opt))
+
+
+def test_affine_alignment_rows_rescore_to_the_affine_score():
+    """Property at a larger batch: re-scoring the emitted rows with the affine model (first gap
+    base open, further ones extend) gives exactly the SW affine score of score_alignments."""
+    import torch
+    R, F, n = 150, 500, 30000
+    reads, refs = synth.make_pairs(n, R, F, seed=62, indel_rate=0.02)
+    aff = hipkernel.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1)
+    eng = hipkernel.Engine(R, F, aff)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    rows, idx = eng.align_device(0, d_reads, d_refs)
+    scores = eng.score_device(0, d_reads, d_refs).cpu().numpy()
+    rows, idx = rows.cpu().numpy(), idx.cpu().numpy()
+    cls = np.zeros(256, np.int64)
+    for ch, c in zip(b"ATCG", (1, 2, 3, 4)):
+        cls[ch] = c
+        cls[ch | 0x20] = c
+    AL = R + F
+    for i in range(0, n, 101):
+        s = idx[i, 0]
+        a, b = rows[i, 0, s:AL - 1], rows[i, 1, s:AL - 1]
+        total, prev = 0, 0            # prev: 0 none/diag, 1 gap in read row, 2 gap in ref row
+        for x, y in zip(a, b):
+            if x == ord("-"):
+                total += -1 if prev == 1 else -5
+                prev = 1
+            elif y == ord("-"):
+                total += -1 if prev == 2 else -5
+                prev = 2
+            else:
+                cx, cy = cls[x], cls[y]
+                total += (2 if cx == cy else -1) if (cx and cy) else 0
+                prev = 0
+        assert total == scores[i], (i, total, scores[i])
+    eng.close()

@@ -80,3 +80,29 @@ def test_oracle_threads_and_noop():
     b = cpu_ref.score(0, reads, refs, threads=4)
     assert np.array_equal(a, b)
     assert not cpu_ref.score(2, reads, refs).any()       # opt & 0xF == 2: silent no-op
+
+
+def test_affine_alignment_oracle_degenerates_to_the_reference_path():
+    """The Gotoh traceback's tie-breaks (DIAG > gap-in-ref > gap-in-read; open preferred over
+    extend) are chosen so that open == extend == g reproduces the linear alignments, which are
+    pinned to the reference Default kernel by the golden fixtures."""
+    from versalignlib_amd import synth
+    for R, F, seed in ((12, 20, 1), (33, 70, 2), (64, 128, 3), (40, 9, 5)):
+        reads, refs = synth.make_pairs(80, R, F, seed=seed, indel_rate=0.04, n_run_frac=0.1, short_frac=0.15)
+        for gr, gf in ((-3, -3), (-2, -4)):
+            lin = cpu_ref.Scoring.make(2, -1, gr, gf)
+            aff = cpu_ref.Scoring.make(2, -1, gr, gf, gr, gr, gf, gf)
+            for opt in (0, 1):
+                a = cpu_ref.align(opt, reads, refs, lin)
+                b = cpu_ref.align(opt, reads, refs, aff, affine=True)
+                assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_affine_alignment_oracle_known_answer():
+    ref = b"ACGTACGTTTGGCCAAGTCA"
+    read = ref[:8] + ref[12:]
+    reads = np.frombuffer(read, np.uint8)[None, :].copy()
+    refs = np.frombuffer(ref, np.uint8)[None, :].copy()
+    rows, idx = cpu_ref.align(0, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1), affine=True)
+    s = idx[0, 0]
+    assert bytes(rows[0, 0, s:-1]) == b"ACGTACGT----CCAAGTCA" and bytes(rows[0, 1, s:-1]) == ref

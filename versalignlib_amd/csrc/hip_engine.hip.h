@@ -39,7 +39,7 @@ struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][4];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine]
-    const void *fill[2][2];        // alignment fill kernels [alg][gap_read == gap_ref] (linear gap model)
+    const void *fill[2][3];        // alignment fill kernels [alg][linear, symmetric linear, affine]
 };
 
 template <int G, int K>
@@ -53,8 +53,10 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>}},
-                    {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>},
-                     {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>}}};
+                    {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>},
+                     {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -279,20 +281,17 @@ public:
                       short *d_idx, hipStream_t stream) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;
-        if (sc_.affine)
-            throw std::runtime_error("compute_alignments implements the reference's linear gap model only; "
-                                     "unset the score_gap_open_*/extend_* keys");
         if (plan_.long_mode)
             throw std::runtime_error("compute_alignments needs the pair to fit one register sweep (read_length <= 2048, "
                                      "reference resident in LDS); this shape only supports score_alignments");
         check_int16_range(alg);
-        if (alg == kAlgNW && (long long)(R_ + 1) * std::min(sc_.gap_ref, 0) < -32000)
-            throw std::runtime_error("NW alignment border (read_length * score_gap_ref) leaves the int16 range");
+        if (alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000))
+            throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
         const int blocks8 = (F_ + G - 1 + 7) / 8;
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4;
+        const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4 * (sc_.affine ? 2 : 1);
         // Pointer scratch: as much of the batch per launch as memory allows (a 1 M-pair launch keeps
         // the latency-bound traceback kernel at full occupancy), capped at 24 GiB and half the free HBM.
         size_t free_b = 0, total_b = 0;
@@ -304,7 +303,7 @@ public:
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
-        const void *fn = plan_.geo->fill[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0];
+        const void *fn = plan_.geo->fill[alg][sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -327,6 +326,10 @@ public:
             f.mismatch = (short)sc_.mismatch;
             f.gap_read = (short)sc_.gap_read;
             f.gap_ref = (short)sc_.gap_ref;
+            f.open_read = (short)sc_.open_read;
+            f.ext_read = (short)sc_.ext_read;
+            f.open_ref = (short)sc_.open_ref;
+            f.ext_ref = (short)sc_.ext_ref;
             void *fargs[] = {&f};
             const long long blocks = (cnt + ppb - 1) / ppb;
             hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), fargs,
@@ -351,6 +354,11 @@ public:
             t.mismatch = f.mismatch;
             t.gap_read = f.gap_read;
             t.gap_ref = f.gap_ref;
+            t.affine = sc_.affine ? 1 : 0;
+            t.open_read = f.open_read;
+            t.ext_read = f.ext_read;
+            t.open_ref = f.open_ref;
+            t.ext_ref = f.ext_ref;
             void *targs[] = {&t};
             hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
                                       targs, 0, stream),

@@ -44,6 +44,7 @@ struct FillArgs {
     int blocks8;              // 8-step blocks per lane = ceil((F + G - 1) / 8)
     short match, mismatch;
     short gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;     // affine fill only
 };
 
 __device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
@@ -51,6 +52,66 @@ __device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
 }
 __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
     return (s16x2)((u16x2)a * (u16x2)b + (u16x2)c);
+}
+
+// End cell of each of the two pairs of a lane group, from the per-row first arg-max registers
+// (reference rules: DefaultKernel.cpp:252-256 for SW, :307-315 / :381-387 for the NW variant).
+template <int G, int K, int ALG, int NT>
+__device__ __forceinline__ void write_end_cells(const FillArgs &args, const WaveTables &w, const s16x2 (&rb)[NT],
+                                                const s16x2 (&fc)[NT], const int (&ir)[2], const int (&jr)[2],
+                                                int pad_rows, int lane, int grp, int l) {
+    // ---- end cell of each of the two pairs of this group ----
+    const int base_lane = lane - l;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const long long pair = w.pair0 + 2 * grp + half;
+        EndCell out;
+        out.pad = 0;
+        if constexpr (ALG == kAlgSW) {
+            int bv = 0, bq = 0, bcol = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int v = half ? rb[q].y : rb[q].x;
+                const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
+                if (v > bv) {
+                    bv = v;
+                    bq = q;
+                    bcol = c;
+                }
+            }
+            // larger value first, then smaller row: rows are unique per lane so keys are too
+            unsigned key = ((unsigned)bv << 16) | (unsigned)(0xFFFF - (l * K + bq));
+            unsigned kmax = key;
+#pragma unroll
+            for (int dd = G / 2; dd >= 1; dd >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)kmax, dd, kWave);
+                kmax = other > kmax ? other : kmax;
+            }
+            const int p = 0xFFFF - (int)(kmax & 0xFFFF);
+            const int win_lane = p / K;
+            const int col_t = __shfl(bcol, base_lane + win_lane, kWave);
+            out.score = (short)(kmax >> 16);
+            out.read_pos = (short)(p - pad_rows);
+            out.ref_pos = (short)(col_t - win_lane);
+            if (out.score <= 0) {
+                out.read_pos = 0;
+                out.ref_pos = 0;
+            }
+        } else {
+            const int i_end = ir[half] - 1;               // last valid read position (may be -1)
+            int arg_col = 0;
+            if (i_end >= 0) {
+                const int src_l = (i_end + pad_rows) / K;
+                const int mine = ((half ? fc[0].y : fc[0].x) & 0xFFFF) - l;
+                arg_col = __shfl(mine, base_lane + src_l, kWave);
+            }
+            const int last_ref = jr[half] - 1;
+            out.score = 0;
+            out.read_pos = (short)i_end;
+            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+        }
+        if (l == 0 && pair < args.n) args.ends[pair] = out;
+    }
 }
 
 // SYM: gap_read == gap_ref, so one subtract serves both gap directions (as in score_kernel).
@@ -207,59 +268,168 @@ align_fill_kernel(const FillArgs args) {
     for (; t < steady_end; ++t) step(std::false_type{}, t);
     for (; t < steps; ++t) step(std::true_type{}, t);
 
-    // ---- end cell of each of the two pairs of this group ----
-    const int base_lane = lane - l;
+    write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
+}
+
+// Affine-gap (Gotoh) fill -- an extension, the reference has no affine model.  Per cell two
+// 2-bit codes are streamed out: where H came from (0 DIAG, 1 F = gap in the ref, 2 E = gap in the
+// read; priority DIAG > F > E so that open == extend walks the linear path), and whether F / E were
+// extended (bit set) or opened from H (preferred on ties).  Pointer scratch per lane and 8-step
+// block: K dwords of H codes followed by K dwords of gap codes.
+template <int G, int K, int ALG>
+__global__ void __launch_bounds__(256)
+align_fill_affine_kernel(const FillArgs args) {
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R, F = args.F;
+    const int pad_rows = geo::kRows - R;
+
+    WaveTables w;
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+                                args.wave_lds, args.match, args.mismatch, w))
+        return;
+
+    const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;
+
+    s16x2 o_read, e_read, o_ref, e_ref;
+    if (ALG == kAlgSW) {
+        o_read = pk((short)-args.open_read);  e_read = pk((short)-args.ext_read);
+        o_ref = pk((short)-args.open_ref);    e_ref = pk((short)-args.ext_ref);
+    } else {
+        o_read = pk(args.open_read);  e_read = pk(args.ext_read);
+        o_ref = pk(args.open_ref);    e_ref = pk(args.ext_ref);
+    }
+    const s16x2 border_f = pk(ALG == kAlgNW ? kNegInf : (short)0);
+    s16x2 one = pk(1), two = pk(2), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(two), "+v"(four), "+v"(fifteen));
+
+    int ir[2], jr[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const long long pair = w.pair0 + 2 * grp + half;
-        EndCell out;
-        out.pad = 0;
+        int p_local = 2 * grp + half;
+        p_local = p_local > w.last ? w.last : p_local;
+        ir[half] = w.first_bad[2 * p_local];
+        jr[half] = w.first_bad[2 * p_local + 1];
+    }
+
+    s16x2 Hl[K], El[K], code_h[K], code_g[K], acc_h[K], acc_g[K];
+    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    short nw_seed[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const int p = l * K + q;
+        short border = 0;
+        if (ALG == kAlgNW)                         // column 0: a gap of i bases in the ref direction
+            border = p < pad_rows ? (short)0 : (short)(args.open_ref + (p - pad_rows) * args.ext_ref);
+        Hl[q] = pk(border);
+        El[q] = border_f;
+        code_h[q] = code_g[q] = acc_h[q] = acc_g[q] = pk(0);
         if (ALG == kAlgSW) {
-            int bv = 0, bq = 0, bcol = 0;
+            rb[q] = pk(0);
+            fc[q] = pk(0);
+        } else {
+            const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
+            const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
+            sel[q] = s16x2{(short)(ta ? -1 : 0), (short)(tb ? -1 : 0)};
+            if (ta) nw_seed[0] = border;
+            if (tb) nw_seed[1] = border;
+        }
+    }
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};
+        fc[0] = pk((short)l);
+    }
+    s16x2 h_last = Hl[K - 1], f_last = border_f;
+    s16x2 up0 = pk(0);
+    int j = -l;
+
+    const long long pp = w.pair0 / 2 + grp;
+    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * (2 * K);
+
+    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const s16x2 diag0 = up0;
+        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        const unsigned fv = from_prev_lane(as_u32(f_last));
+        const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            const s16x2 tt = pk((short)t);
+            s16x2 d[K], m[K];
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const int v = half ? rb[q].y : rb[q].x;
-                const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
-                if (v > bv) {
-                    bv = v;
-                    bq = q;
-                    bcol = c;
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                const s16x2 e_open = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], o_read) : pk_add_sat(Hl[q], o_read);
+                const s16x2 e_extd = (ALG == kAlgSW) ? pk_sub_floor0(El[q], e_read) : pk_add_sat(El[q], e_read);
+                const s16x2 e = pk_max(e_extd, e_open);
+                El[q] = e;
+                code_g[q] = pk_min_u(e - e_open, one);            // 1: E extended, 0: opened from H
+                m[q] = pk_max(d[q], e);
+            }
+            s16x2 h = up0, f = fup0;
+            s16x2 hs = pk(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 f_open = (ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref);
+                const s16x2 f_extd = (ALG == kAlgSW) ? pk_sub_floor0(f, e_ref) : pk_add_sat(f, e_ref);
+                f = pk_max(f_extd, f_open);
+                h = pk_max(m[q], f);
+                Hl[q] = h;
+                const s16x2 nd = pk_min_u(h - d[q], one);
+                const s16x2 nf = pk_min_u(h - f, one);
+                code_h[q] = pk_mad_u(nd, nf, nd);                 // 0 DIAG, 1 from F, 2 from E
+                code_g[q] = pk_mad_u(code_g[q], two, pk_min_u(f - f_open, one));   // bit1 E extended, bit0 F extended
+                if (ALG == kAlgSW) {
+                    const s16x2 nb = pk_max(rb[q], h);
+                    const s16x2 changed = (rb[q] - nb) >> fifteen;
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = nb;
+                } else {
+                    hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
                 }
             }
-            // larger value first, then smaller row: rows are unique per lane so keys are too
-            unsigned key = ((unsigned)bv << 16) | (unsigned)(0xFFFF - (l * K + bq));
-            unsigned kmax = key;
-#pragma unroll
-            for (int dd = G / 2; dd >= 1; dd >>= 1) {
-                const unsigned other = (unsigned)__shfl_xor((int)kmax, dd, kWave);
-                kmax = other > kmax ? other : kmax;
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
             }
-            const int p = 0xFFFF - (int)(kmax & 0xFFFF);
-            const int win_lane = p / K;
-            const int col_t = __shfl(bcol, base_lane + win_lane, kWave);
-            out.score = (short)(kmax >> 16);
-            out.read_pos = (short)(p - pad_rows);
-            out.ref_pos = (short)(col_t - win_lane);
-            if (out.score <= 0) {
-                out.read_pos = 0;
-                out.ref_pos = 0;
-            }
-        } else {
-            const int i_end = ir[half] - 1;               // last valid read position (may be -1)
-            int arg_col = 0;
-            if (i_end >= 0) {
-                const int src_l = (i_end + pad_rows) / K;
-                const int mine = ((half ? fc[0].y : fc[0].x) & 0xFFFF) - l;
-                arg_col = __shfl(mine, base_lane + src_l, kWave);
-            }
-            const int last_ref = jr[half] - 1;
-            out.score = 0;
-            out.read_pos = (short)i_end;
-            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+            h_last = h;
+            f_last = f;
         }
-        if (l == 0 && pair < args.n) args.ends[pair] = out;
-    }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            acc_h[q] = pk_mad_u(acc_h[q], four, code_h[q]);
+            acc_g[q] = pk_mad_u(acc_g[q], four, code_g[q]);
+        }
+        if ((t & 7) == 7) {
+            unsigned *dst = ptr_lane + (long long)(t >> 3) * (2 * K);
+#pragma unroll
+            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc_h[q]);
+#pragma unroll
+            for (int q = 0; q < K; ++q) dst[K + q] = as_u32(acc_g[q]);
+        }
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = args.blocks8 * 8;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t < steady_end; ++t) step(std::false_type{}, t);
+    for (; t < steps; ++t) step(std::true_type{}, t);
+
+    write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
 }
+
 
 struct TraceArgs {
     const uint8_t *reads;
@@ -272,7 +442,9 @@ struct TraceArgs {
     int R, F;
     int G, K, pad_rows, blocks8;
     int alg;
+    int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
     short match, mismatch, gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;
 };
 
 typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
@@ -285,23 +457,25 @@ traceback_kernel(const TraceArgs a) {
     const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= a.n) return;
     const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
+    const int wpb = a.affine ? 2 * K : K;                         // words per lane and 8-step block
     const uint8_t *read = a.reads + pair * R;
     const uint8_t *ref = a.refs + pair * F;
     uint8_t *row_read = a.rows + pair * 2 * AL;
     uint8_t *row_ref = row_read + AL;
     const EndCell e = a.ends[pair];
-    const unsigned *ptr_pair = a.ptr + ((pair >> 1) * G) * (long long)a.blocks8 * K;
-    const long long ptr_words = (long long)G * a.blocks8 * K;     // words of this pair-of-pairs
+    const unsigned *ptr_pair = a.ptr + ((pair >> 1) * G) * (long long)a.blocks8 * wpb;
+    const long long ptr_words = (long long)G * a.blocks8 * wpb;   // words of this pair-of-pairs
     const int half_shift = (int)(pair & 1) * 16;
 
     int i = e.read_pos, j = e.ref_pos, h = e.score;
     int k = AL - 2;
-    long long cached_at = -1;              // first word index held in `cache` (multiple of 4)
+    long long cached_at = -1;              // first word index held in c0..c3 (multiple of 4)
     unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     int rd_at = -1, rf_at = -1;            // index / 4 of the cached read / ref dwords
     unsigned rd_w = 0, rf_w = 0;
     unsigned out_r = 0, out_f = 0;         // up to 4 pending output bytes per row, newest in the low byte
     int pending = 0;
+    int state = 0;                         // affine only: 0 at H, 1 inside F (gap in the ref), 2 inside E
 
     auto base_at = [](const uint8_t *seq, int len, int pos, int &at, unsigned &w) -> unsigned {
         if ((pos >> 2) != at) {
@@ -316,37 +490,60 @@ traceback_kernel(const TraceArgs a) {
         }
         return (w >> (8 * (pos & 3))) & 0xFFu;
     };
+    // 2-bit code of cell (i, j) from word `wi` of this pair-of-pairs, through a 4-word cache
+    auto code_at = [&](long long wi, int t) -> int {
+        const long long wb = wi & ~3ll;
+        if (wb != cached_at) {
+            cached_at = wb;
+            if (wb + 4 <= ptr_words) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
+                c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+            } else {
+                c0 = ptr_pair[wb];
+                c1 = wb + 1 < ptr_words ? ptr_pair[wb + 1] : 0u;
+                c2 = wb + 2 < ptr_words ? ptr_pair[wb + 2] : 0u;
+                c3 = 0u;
+            }
+        }
+        const int sel = (int)(wi & 3);
+        const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
+        return (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
+    };
 
     while (k >= 0) {
-        int move;                                   // 0 DIAG, 1 UP, 2 LEFT
-        if (a.alg == kAlgSW) {
-            if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
-        } else {
-            if (i < 0) break;                       // row 0: START
+        if (state == 0) {
+            if (a.alg == kAlgSW) {
+                if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
+            } else {
+                if (i < 0) break;                       // row 0: START
+            }
         }
+        int move;                                       // 0 DIAG, 1 UP (emit read, '-'), 2 LEFT
         if (j < 0) {
-            move = 1;                               // column 0 of the NW variant: UP
+            move = 1;                                   // column 0 of the NW variant: UP all the way
+            state = 0;
         } else {
             const int p = i + a.pad_rows;
             const int l = p / K, q = p - l * K;
             const int t = j + l;
-            const long long wi = ((long long)l * a.blocks8 + (t >> 3)) * K + q;
-            const long long wb = wi & ~3ll;
-            if (wb != cached_at) {
-                cached_at = wb;
-                if (wb + 4 <= ptr_words) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
-                    c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+            const long long wi = ((long long)l * a.blocks8 + (t >> 3)) * wpb + q;
+            if (!a.affine) {
+                move = code_at(wi, t);
+            } else if (state == 0) {
+                move = code_at(wi, t);                  // 0 DIAG, 1 enter F, 2 enter E
+                if (move != 0) {
+                    state = move;                       // nothing is emitted on entering a gap state
+                    continue;
+                }
+            } else {
+                const int bits = code_at(wi + K, t);    // bit0: F extended, bit1: E extended
+                move = state;
+                if (state == 1) {
+                    if (bits & 1) h -= a.ext_ref; else { h -= a.open_ref; state = 0; }
                 } else {
-                    c0 = ptr_pair[wb];
-                    c1 = wb + 1 < ptr_words ? ptr_pair[wb + 1] : 0u;
-                    c2 = wb + 2 < ptr_words ? ptr_pair[wb + 2] : 0u;
-                    c3 = 0u;
+                    if (bits & 2) h -= a.ext_read; else { h -= a.open_read; state = 0; }
                 }
             }
-            const int sel = (int)(wi & 3);
-            const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
-            move = (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
         }
         unsigned br, bf;
         if (move == 0) {
@@ -359,24 +556,24 @@ traceback_kernel(const TraceArgs a) {
         } else if (move == 1) {
             br = base_at(read, R, i, rd_at, rd_w);
             bf = '-';
-            h -= a.gap_ref;
+            if (!a.affine) h -= a.gap_ref;
             --i;
         } else {
             br = '-';
             bf = base_at(ref, F, j, rf_at, rf_w);
-            h -= a.gap_read;
+            if (!a.affine) h -= a.gap_read;
             --j;
         }
         out_r = (out_r << 8) | br;
         out_f = (out_f << 8) | bf;
-        if (++pending == 4) {                       // bytes k .. k+3 of both rows, lowest address = newest
+        if (++pending == 4) {                           // bytes k .. k+3 of both rows, lowest address = newest
             *reinterpret_cast<u32_any_align *>(row_read + k) = out_r;
             *reinterpret_cast<u32_any_align *>(row_ref + k) = out_f;
             pending = 0;
         }
         --k;
     }
-    for (int x = 0; x < pending; ++x) {             // k + 1 is the newest byte written
+    for (int x = 0; x < pending; ++x) {                 // k + 1 is the newest byte written
         row_read[k + 1 + x] = (uint8_t)(out_r >> (8 * x));
         row_ref[k + 1 + x] = (uint8_t)(out_f >> (8 * x));
     }
