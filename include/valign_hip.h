@@ -17,6 +17,8 @@
  *     Optional keys, probed with has_key (a reference host simply lacks them):
  *       score_gap_open_read / score_gap_extend_read /
  *       score_gap_open_ref  / score_gap_extend_ref ... affine-gap extension (scores and alignments)
+ *       traceback_policy ................................ 0 Default/OpenCL tie-breaks (default),
+ *                                                         1 SSE2/AVX2 tie-breaks (linear gaps)
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
@@ -69,6 +71,11 @@ int valign_hip_engine_create(int device, int read_length, int ref_length,
                              const valign_hip_scoring *scoring, int force_group_lanes,
                              int force_rows_per_lane, valign_hip_engine **out);
 void valign_hip_engine_destroy(valign_hip_engine *e);
+
+/* Tie-break rules of compute_alignments: 0 = the reference's Default/OpenCL kernels (default),
+ * 1 = its SSE2/AVX2 kernels (DIAG only between ACGT bases > LEFT > UP, no stop at zero cells,
+ * N invalid for the NW end cell; src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 532-536).          */
+int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and
  * d_refs = n*ref_length bytes (raw ASCII, pair-major, NUL padded), d_scores = n int16.

@@ -451,6 +451,91 @@ int vref_align_affine(int opt, int n, int R, int F, const uint8_t *reads, const 
     return n;
 }
 
+/* ---- second tie-break policy: the reference's SSE2 / AVX2 kernels ----
+ * Same cell values, different pointers (src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 646-659):
+ *   pointer = DIAG if the cell equals diag+S AND both bases are in ACGT, else LEFT if it equals
+ *   left+gap_read, else UP if it equals up+gap_ref, else START -- there is no "cell == 0 -> START"
+ *   rule, so a Smith-Waterman traceback walks through zero cells, and a cell whose only source
+ *   is a diagonal over a non-ACGT base stops the traceback.  For the NW variant's end cell a
+ *   base is "invalid" when it is not in ACGT (N counts as invalid; SSEKernel.cpp:532-536,
+ *   673-677), otherwise the bookkeeping is the Default kernel's.  Row 0 is START, column 0 is
+ *   UP (NW) / START (SW).                                                                    */
+static int valid_acgt(uint8_t ch) { const int c = g_class[ch]; return c >= 1 && c <= 4; }
+
+static void sse_fill(int alg, const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                     int16_t gr, int16_t gf, int16_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
+    int16_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));
+    int16_t best = 0; int bi = 0, bj = 0;
+    int16_t last_read = (int16_t)(R - 1), last_ref = (int16_t)(F - 1);
+    int16_t row_best = INT16_MIN, row_arg = 0, snap_arg = -1;
+    for (int i = 0; i < R; ++i) {
+        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
+        const int vr = valid_acgt(read[i]);
+        if (alg == 1) {
+            prow[0] = PTR_UP;
+            cur[0] = (int16_t)((i + 1) * gf);
+            if (last_read == R - 1 && !vr) last_read = (int16_t)(i - 1);
+            if (last_read + 1 == i) snap_arg = row_arg;
+            row_best = cur[0]; row_arg = 0;
+        }
+        const int16_t *srow = tab[g_class[read[i]]];
+        for (int j = 0; j < F; ++j) {
+            const int16_t up = (int16_t)(prev[j + 1] + gf), left = (int16_t)(cur[j] + gr);
+            const int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
+            int16_t h = max16(diag, max16(left, up));
+            if (alg == 0) h = max16(h, 0);
+            cur[j + 1] = h;
+            uint8_t p = PTR_START;
+            if (h == up) p = PTR_UP;
+            if (h == left) p = PTR_LEFT;
+            if (h == diag && vr && valid_acgt(ref[j])) p = PTR_DIAG;
+            prow[j + 1] = p;
+            if (alg == 0) {
+                if (h > best) { best = h; bi = i; bj = j; }
+            } else {
+                if (last_ref == F - 1 && !valid_acgt(ref[j])) last_ref = (int16_t)(j - 1);
+                if (h > row_best) { row_best = h; row_arg = (int16_t)j; }
+            }
+        }
+        int16_t *t = prev; prev = cur; cur = t;
+    }
+    if (alg == 0) { *end_i = bi; *end_j = bj; }
+    else {
+        if (snap_arg < 0) snap_arg = row_arg;
+        *end_i = last_read;
+        *end_j = last_ref < snap_arg ? last_ref : snap_arg;
+    }
+}
+
+int vref_align_sse(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                   const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int16_t gr = (int16_t)sc->gap_read, gf = (int16_t)sc->gap_ref;
+    const int alg = opt & 0xF, AL = R + F;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t *rows = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(F + 1));
+        uint8_t *ptr = (uint8_t *)malloc((size_t)(R + 1) * (F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(ptr, PTR_START, (size_t)(R + 1) * (F + 1));
+            int ei, ej;
+            sse_fill(alg, rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
+            traceback(rd, rf, R, F, ptr, ei, ej, rows_out + (size_t)p * 2 * AL,
+                      rows_out + (size_t)p * 2 * AL + AL, idx_out + (size_t)p * 4);
+        }
+        free(ptr);
+        free(rows);
+    }
+    return n;
+}
+
 int vref_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -169,3 +169,44 @@ def test_affine_alignment_rows_rescore_to_the_affine_score():
                 prev = 0
         assert total == scores[i], (i, total, scores[i])
     eng.close()
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(64, 128, 400, 41), (150, 500, 203, 42), (33, 70, 201, 43), (16, 16, 64, 44)])
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_sse_traceback_policy(R, F, n, seed, gaps):
+    """traceback_policy = 1: the tie-breaks of the reference's SSE2/AVX2 kernels."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.15, short_frac=0.12,
+                                   lowercase_frac=0.05, junk_frac=0.05)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1],
+                     traceback_policy=1) as hip:
+        for opt in (0, 1):
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            _assert_same(got, cpu_ref.align(opt, reads, refs, sc, threads=8, policy="sse"), ("sse", opt))
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files() if "kat" not in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_sse_policy_matches_sse_kernel_fixtures(path):
+    g = load(path)
+    R, F = g["reads"].shape[1], g["refs"].shape[1]
+    m, x, gr, gf = (int(v) for v in g["scoring"])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=m, score_mismatch=x, score_gap_read=gr,
+                     score_gap_ref=gf, traceback_policy=1) as hip:
+        for opt, tag in ((0, "sw"), (1, "nw")):
+            n8 = g["sse_idx_" + tag].shape[0]
+            got = hip.compute_alignments(opt, g["reads"][:n8], g["refs"][:n8], normalise=False)
+            _assert_same(got, (g["sse_rows_" + tag], g["sse_idx_" + tag]), (path, tag))
+
+
+def test_sse_policy_live_against_sse_and_avx_kernels():
+    sse, avx = ref_kernel("SSE"), ref_kernel("AVX")
+    if not sse or not avx:
+        pytest.skip("oracle/_ref not built")
+    R, F, n = 150, 500, 160
+    reads, refs = synth.make_pairs(n, R, F, seed=93, indel_rate=0.02, n_run_frac=0.1, short_frac=0.08)
+    with host.Plugin(build.HIP_PLUGIN, R, F, traceback_policy=1) as hip, host.Plugin(sse, R, F) as s, \
+            host.Plugin(avx, R, F) as a:
+        for opt in (0, 1):
+            got = hip.compute_alignments(opt, reads, refs)
+            _assert_same(got, s.compute_alignments(opt, reads, refs), ("sse", opt))
+            _assert_same(got, a.compute_alignments(opt, reads, refs), ("avx", opt))

@@ -106,3 +106,18 @@ def test_affine_alignment_oracle_known_answer():
     rows, idx = cpu_ref.align(0, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1), affine=True)
     s = idx[0, 0]
     assert bytes(rows[0, 0, s:-1]) == b"ACGTACGT----CCAAGTCA" and bytes(rows[0, 1, s:-1]) == ref
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files() if "kat" not in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_sse_policy_oracle_reproduces_the_sse_kernel(path):
+    """Second tie-break policy: alignments of the reference's SSE2 kernel."""
+    g = load(path)
+    m, x, gr, gf = (int(v) for v in g["scoring"])
+    sc = cpu_ref.Scoring.make(m, x, gr, gf)
+    differs = 0
+    for opt, tag in ((0, "sw"), (1, "nw")):
+        n8 = g["sse_idx_" + tag].shape[0]
+        rows, idx = cpu_ref.align(opt, g["reads"][:n8], g["refs"][:n8], sc, policy="sse")
+        assert np.array_equal(idx, g["sse_idx_" + tag]) and np.array_equal(rows, g["sse_rows_" + tag])
+        differs += int((idx != g["idx_" + tag][:n8]).any(axis=1).sum())
+    assert differs > 0 or "c2" in path        # the fixtures do exercise the difference to the Default policy

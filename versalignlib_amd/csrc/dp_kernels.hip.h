@@ -191,7 +191,7 @@ struct WaveTables {
 template <int G, int K, bool FIND_BAD>
 __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
                                            int prof_area, int refc_stride, int wave_lds, short match,
-                                           short mismatch, WaveTables &w) {
+                                           short mismatch, WaveTables &w, bool bad_is_non_acgt = false) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -245,8 +245,9 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab);
             dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab);
             if (FIND_BAD) {
-                if (ca == 0) atomicMin(&first_bad[2 * (2 * g) + 1], j);
-                if (cb == 0) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
+                // "invalid" for the NW end cell: class 0 (Default kernel) or anything but ACGT (SSE kernel)
+                if (ca == 0 || (bad_is_non_acgt && ca == 5)) atomicMin(&first_bad[2 * (2 * g) + 1], j);
+                if (cb == 0 || (bad_is_non_acgt && cb == 5)) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
             }
         }
     }
@@ -259,7 +260,8 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             const int idx = lane + kWave * i;
             const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
             const int a = rr >= pad_rows ? base_class(rd[i]) : 0;
-            if (FIND_BAD && rr >= pad_rows && a == 0) atomicMin(&first_bad[2 * p], rr - pad_rows);
+            if (FIND_BAD && rr >= pad_rows && (a == 0 || (bad_is_non_acgt && a == 5)))
+                atomicMin(&first_bad[2 * p], rr - pad_rows);
             const bool valid = a >= 1 && a <= 4;
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll

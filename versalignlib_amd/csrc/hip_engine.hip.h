@@ -39,7 +39,7 @@ struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][4];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine]
-    const void *fill[2][3];        // alignment fill kernels [alg][linear, symmetric linear, affine]
+    const void *fill[2][4];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy]
 };
 
 template <int G, int K>
@@ -54,9 +54,9 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>},
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>}}};
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -121,6 +121,11 @@ public:
         }
     }
 
+    // 0: Default/OpenCL kernel tie-breaks (default); 1: SSE2/AVX2 kernel tie-breaks
+    void set_traceback_policy(int policy) {
+        if (policy != 0 && policy != 1) throw std::runtime_error("traceback_policy must be 0 (default) or 1 (sse)");
+        sse_policy_ = policy == 1;
+    }
     int device() const { return device_; }
     const LaunchPlan &plan() const { return plan_; }
     hipStream_t own_stream() const { return streams_[0]; }
@@ -303,7 +308,9 @@ public:
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
-        const void *fn = plan_.geo->fill[alg][sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)];
+        if (sse_policy_ && sc_.affine)
+            throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
+        const void *fn = plan_.geo->fill[alg][sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -355,6 +362,7 @@ public:
             t.gap_read = f.gap_read;
             t.gap_ref = f.gap_ref;
             t.affine = sc_.affine ? 1 : 0;
+            t.sse_policy = sse_policy_ ? 1 : 0;
             t.open_read = f.open_read;
             t.ext_read = f.ext_read;
             t.open_ref = f.open_ref;
@@ -630,6 +638,7 @@ private:
 
     int device_, R_, F_;
     Scoring sc_;
+    bool sse_policy_ = false;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     std::string arch_;
     LaunchPlan plan_;

@@ -66,6 +66,7 @@ public:
         try {
             engine_.reset(new valign::Engine(opt_param("hip_device", 0), R, F, sc, opt_param("hip_group_lanes", 0),
                                              opt_param("hip_rows_per_lane", 0)));
+            engine_->set_traceback_policy(opt_param("traceback_policy", 0));
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
@@ -182,6 +183,14 @@ VALIGN_EXPORT int valign_hip_engine_create(int device, int read_length, int ref_
 }
 
 VALIGN_EXPORT void valign_hip_engine_destroy(valign_hip_engine *e) { delete e; }
+
+VALIGN_EXPORT int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_traceback_policy(policy); });
+}
 
 VALIGN_EXPORT int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
                                           const void *d_refs, void *d_scores, void *hip_stream) {

@@ -431,6 +431,152 @@ align_fill_affine_kernel(const FillArgs args) {
 }
 
 
+// Second tie-break policy: the reference's SSE2/AVX2 kernels (SSEKernel.cpp:366-379, 646-659).
+// Stored states: 0 START, 1 UP, 2 LEFT, 3 DIAG; DIAG only between two ACGT bases, then LEFT, then UP,
+// else START -- no "cell == 0 -> START" rule.  Cells are computed in the signed form (the equality
+// tests are against the un-floored up+gap / left+gap), so the zero floor is an explicit max.
+template <int G, int K, int ALG>
+__global__ void __launch_bounds__(256)
+align_fill_sse_kernel(const FillArgs args) {
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R, F = args.F;
+    const int pad_rows = geo::kRows - R;
+
+    WaveTables w;
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+                                args.wave_lds, args.match, args.mismatch, w, true))
+        return;
+
+    const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;
+
+    const s16x2 g_read = pk(args.gap_read), g_ref = pk(args.gap_ref);
+    s16x2 one = pk(1), three = pk(3), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(three), "+v"(four), "+v"(fifteen));
+
+    int ir[2], jr[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int p_local = 2 * grp + half;
+        p_local = p_local > w.last ? w.last : p_local;
+        ir[half] = w.first_bad[2 * p_local];
+        jr[half] = w.first_bad[2 * p_local + 1];
+    }
+
+    s16x2 Hl[K], code[K], acc[K], rinv[K];
+    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    short nw_seed[2] = {0, 0};
+    {
+        int pa = 2 * grp, pb = 2 * grp + 1;
+        pa = pa > w.last ? w.last : pa;
+        pb = pb > w.last ? w.last : pb;
+        const uint8_t *ra = args.reads + (w.pair0 + pa) * R, *rbp = args.reads + (w.pair0 + pb) * R;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int p = l * K + q;
+            const int grow = p - pad_rows;
+            const int ca = grow >= 0 ? base_class(ra[grow]) : 0, cb = grow >= 0 ? base_class(rbp[grow]) : 0;
+            rinv[q] = s16x2{(short)((ca >= 1 && ca <= 4) ? 0 : 1), (short)((cb >= 1 && cb <= 4) ? 0 : 1)};
+            short border = 0;
+            if (ALG == kAlgNW) border = p < pad_rows ? (short)0 : (short)((p - pad_rows + 1) * args.gap_ref);
+            Hl[q] = pk(border);
+            code[q] = pk(0);
+            acc[q] = pk(0);
+            if (ALG == kAlgSW) {
+                rb[q] = pk(0);
+                fc[q] = pk(0);
+            } else {
+                const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
+                const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
+                sel[q] = s16x2{(short)(ta ? -1 : 0), (short)(tb ? -1 : 0)};
+                if (ta) nw_seed[0] = border;
+                if (tb) nw_seed[1] = border;
+            }
+        }
+    }
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};
+        fc[0] = pk((short)l);
+    }
+    s16x2 h_last = Hl[K - 1];
+    s16x2 up0 = pk(0);
+    int j = -l;
+
+    const long long pp = w.pair0 / 2 + grp;
+    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+
+    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const s16x2 diag0 = up0;
+        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            // 1 where the reference base of the pair is not ACGT (those columns use the zero slab)
+            const s16x2 cinv = as_pk((ca == (unsigned)geo::kZeroSlab ? 1u : 0u) | (cb == (unsigned)geo::kZeroSlab ? 0x10000u : 0u));
+            const s16x2 tt = pk((short)t);
+            s16x2 d[K], lg[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                lg[q] = Hl[q] + g_read;
+            }
+            s16x2 h = up0;
+            s16x2 hs = pk(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 ug = h + g_ref;
+                h = pk_max(pk_max(d[q], lg[q]), ug);
+                if (ALG == kAlgSW) h = pk_max(h, pk(0));
+                Hl[q] = h;
+                const s16x2 nu = pk_min_u(h - ug, one), nl = pk_min_u(h - lg[q], one);
+                const s16x2 ndv = pk_max(pk_max(pk_min_u(h - d[q], one), rinv[q]), cinv);
+                const s16x2 t1 = pk_mad_u(nl, nu, nl);
+                code[q] = three - pk_mad_u(ndv, t1, ndv);          // 3 DIAG, 2 LEFT, 1 UP, 0 START
+                if (ALG == kAlgSW) {
+                    const s16x2 nb = pk_max(rb[q], h);
+                    const s16x2 changed = (rb[q] - nb) >> fifteen;
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = nb;
+                } else {
+                    hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
+                }
+            }
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = h;
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
+        if ((t & 7) == 7) {
+            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
+#pragma unroll
+            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+        }
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = args.blocks8 * 8;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t < steady_end; ++t) step(std::false_type{}, t);
+    for (; t < steps; ++t) step(std::true_type{}, t);
+
+    write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
+}
+
 struct TraceArgs {
     const uint8_t *reads;
     const uint8_t *refs;
@@ -443,6 +589,7 @@ struct TraceArgs {
     int G, K, pad_rows, blocks8;
     int alg;
     int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
+    int sse_policy;           // 1: stored states are 0 START, 1 UP, 2 LEFT, 3 DIAG (SSE/AVX kernel rules)
     short match, mismatch, gap_read, gap_ref;
     short open_read, ext_read, open_ref, ext_ref;
 };
@@ -512,7 +659,9 @@ traceback_kernel(const TraceArgs a) {
 
     while (k >= 0) {
         if (state == 0) {
-            if (a.alg == kAlgSW) {
+            if (a.sse_policy) {
+                if (i < 0 || (a.alg == kAlgSW && j < 0)) break;      // row 0 (and SW column 0): START
+            } else if (a.alg == kAlgSW) {
                 if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
             } else {
                 if (i < 0) break;                       // row 0: START
@@ -527,7 +676,11 @@ traceback_kernel(const TraceArgs a) {
             const int l = p / K, q = p - l * K;
             const int t = j + l;
             const long long wi = ((long long)l * a.blocks8 + (t >> 3)) * wpb + q;
-            if (!a.affine) {
+            if (a.sse_policy) {
+                const int st = code_at(wi, t);          // 0 START, 1 UP, 2 LEFT, 3 DIAG
+                if (st == 0) break;
+                move = st == 3 ? 0 : st;
+            } else if (!a.affine) {
                 move = code_at(wi, t);
             } else if (state == 0) {
                 move = code_at(wi, t);                  // 0 DIAG, 1 enter F, 2 enter E

@@ -59,6 +59,7 @@ def lib():
                                                ctypes.POINTER(vp)]
         L.valign_hip_engine_destroy.restype = None
         L.valign_hip_engine_destroy.argtypes = [vp]
+        L.valign_hip_set_traceback_policy.argtypes = [vp, ctypes.c_int]
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
         L.valign_hip_align_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp, vp]
         L.valign_hip_score_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int]
@@ -72,7 +73,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -94,6 +95,11 @@ class Engine:
                                             int(rows_per_lane), ctypes.byref(self._h))
         if rc != 0:
             self._h = None
+            raise HipKernelError(_err())
+
+    def set_traceback_policy(self, policy):
+        """0: Default-kernel tie-breaks (default); 1: SSE/AVX-kernel tie-breaks."""
+        if lib().valign_hip_set_traceback_policy(self._h, int(policy)) != 0:
             raise HipKernelError(_err())
 
     def score_device(self, opt, reads, refs, scores=None, stream=None):
