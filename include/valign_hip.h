@@ -19,6 +19,8 @@
  *       score_gap_open_ref  / score_gap_extend_ref ... affine-gap extension (scores and alignments)
  *       traceback_policy ................................ 0 Default/OpenCL tie-breaks (default),
  *                                                         1 SSE2/AVX2 tie-breaks (linear gaps)
+ *       band_width ...................................... > 0: banded Smith-Waterman scores, that
+ *                                                         many diagonals around the main one (strip band)
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
@@ -76,6 +78,12 @@ void valign_hip_engine_destroy(valign_hip_engine *e);
  * 1 = its SSE2/AVX2 kernels (DIAG only between ACGT bases > LEFT > UP, no stop at zero cells,
  * N invalid for the NW end cell; src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 532-536).          */
 int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
+
+/* Banded Smith-Waterman scores: rows are processed in strips of 160; a strip only sweeps the
+ * columns within diagonals/2 of the (scaled) main diagonal through its rows and every cell
+ * outside those rectangles counts as 0.  0 (default) computes every cell; a band wider than the
+ * matrix gives the unbanded result.  An extension: the reference has no banding.                 */
+int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and
  * d_refs = n*ref_length bytes (raw ASCII, pair-major, NUL padded), d_scores = n int16.

@@ -54,3 +54,32 @@ def test_config5_shape_10k_by_10k():
     exp = cpu_ref.score(0, reads, refs, threads=8)
     assert np.array_equal(got, exp), (got, exp)
     assert exp.max() > 10000          # the batch does exercise large cell values
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(400, 450, 120, 1), (1000, 1300, 33, 2), (150, 500, 203, 3), (3000, 2800, 10, 4)])
+@pytest.mark.parametrize("band", [16, 64, 512, 100000])
+def test_banded_smith_waterman(R, F, n, seed, band):
+    """band_width: strip-banded SW scores (extension, own oracle); a band wider than the matrix
+    is the unbanded result, i.e. the reference's."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band) as hip:
+        got = hip.score_alignments(0, reads, refs)
+        assert '"band_width": %d' % band in hip.drain_log()
+        with pytest.raises(host.PluginError, match="Smith-Waterman scores only"):
+            hip.score_alignments(1, reads, refs)
+    exp = cpu_ref.score_banded_sw(reads, refs, band, threads=8)
+    assert np.array_equal(got, exp), (np.nonzero(got != exp)[0][:8], got[:8], exp[:8])
+    if band >= 2 * max(R, F):
+        assert np.array_equal(got, cpu_ref.score(0, reads, refs, threads=8))
+
+
+def test_config5_banded_10k():
+    """BASELINE config 5 as stated: 10 kbp x 10 kbp, band of 512 diagonals."""
+    R = F = 10000
+    n = 24
+    reads, refs = synth.make_pairs(n, R, F, seed=56, sub_rate=0.1, indel_rate=0.0, n_run_frac=0.2, short_frac=0.1)
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, 512, threads=8))
+    full = cpu_ref.score(0, reads[:4], refs[:4], threads=8)
+    assert (got[:4] <= full).all()

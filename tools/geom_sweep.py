@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--geoms", default="0x0,8x20,16x10,16x12,32x8,64x12")
     ap.add_argument("--affine", type=int, default=0)
     ap.add_argument("--opt", type=int, default=0)
+    ap.add_argument("--band", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
@@ -37,6 +38,8 @@ def main():
         except hipkernel.HipKernelError as e:
             print(geom, "unavailable:", e)
             continue
+        if a.band:
+            eng.set_band_width(a.band)
         out = eng.score_device(a.opt, reads, refs)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -121,6 +121,14 @@ public:
         }
     }
 
+    // Banded Smith-Waterman scores (strip band of long_kernels.hip.h); 0 = every cell.  Takes the
+    // long-read path whatever the shape.
+    void set_band_width(int diagonals) {
+        if (diagonals < 0) throw std::runtime_error("band_width must be >= 0");
+        band_width_ = diagonals;
+        if (diagonals > 0 && !plan_.long_mode) plan_ = long_plan();
+    }
+    int band_width() const { return band_width_; }
     // 0: Default/OpenCL kernel tie-breaks (default); 1: SSE2/AVX2 kernel tie-breaks
     void set_traceback_policy(int policy) {
         if (policy != 0 && policy != 1) throw std::runtime_error("traceback_policy must be 0 (default) or 1 (sse)");
@@ -182,6 +190,8 @@ public:
     // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
     void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
                            hipStream_t stream) {
+        if (band_width_ > 0 && alg != kAlgSW)
+            throw std::runtime_error("band_width applies to Smith-Waterman scores only");
         if (sc_.affine)
             throw std::runtime_error("the long-read path implements the linear gap model only (read_length " +
                                      std::to_string(R_) + " needs row strips)");
@@ -192,6 +202,7 @@ public:
         a.F = F_;
         a.strips = std::max(1, (R_ + rows - 1) / rows);
         a.row_dwords = ((F_ + kLongG + kPhase - 1) / kPhase) * kPhase + kPhase;
+        a.band_half = (band_width_ > 0 && alg == kAlgSW) ? band_width_ / 2 : -1;
         a.match = (short)sc_.match;
         a.mismatch = (short)sc_.mismatch;
         a.gap_read = (short)sc_.gap_read;
@@ -424,11 +435,12 @@ public:
         snprintf(buf, sizeof buf,
                  "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
-                 "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d}",
+                 "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
+                 "\"band_width\": %d}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
-                 plan_.long_mode ? 1 : 0);
+                 plan_.long_mode ? 1 : 0, band_width_);
         return buf;
     }
 
@@ -493,16 +505,20 @@ private:
             if (force_g || force_k)
                 throw std::runtime_error("the forced kernel geometry does not fit read_length=" + std::to_string(R_) +
                                          ", ref_length=" + std::to_string(F_));
-            LaunchPlan p;                  // row strips + column phases: any length the ABI allows
-            p.long_mode = true;
-            p.pairs_per_wave = 2 * (kWave / kLongG);
-            p.waves_per_block = 1;
-            p.lds.total = LongLds<kLongG, kLongK>::kTotal;
-            for (int i = 0; i < kNumGeometries; ++i)
-                if (kGeometries[i].G == kLongG && kGeometries[i].K == kLongK) p.geo = &kGeometries[i];
-            return p;
+            return long_plan();
         }
         return best;
+    }
+
+    static LaunchPlan long_plan() {        // row strips + column phases: any length the ABI allows
+        LaunchPlan p;
+        p.long_mode = true;
+        p.pairs_per_wave = 2 * (kWave / kLongG);
+        p.waves_per_block = 1;
+        p.lds.total = LongLds<kLongG, kLongK>::kTotal;
+        for (int i = 0; i < kNumGeometries; ++i)
+            if (kGeometries[i].G == kLongG && kGeometries[i].K == kLongK) p.geo = &kGeometries[i];
+        return p;
     }
 
 
@@ -639,6 +655,7 @@ private:
     int device_, R_, F_;
     Scoring sc_;
     bool sse_policy_ = false;
+    int band_width_ = 0;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     std::string arch_;
     LaunchPlan plan_;

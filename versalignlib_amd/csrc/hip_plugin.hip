@@ -67,6 +67,7 @@ public:
             engine_.reset(new valign::Engine(opt_param("hip_device", 0), R, F, sc, opt_param("hip_group_lanes", 0),
                                              opt_param("hip_rows_per_lane", 0)));
             engine_->set_traceback_policy(opt_param("traceback_policy", 0));
+            engine_->set_band_width(opt_param("band_width", 0));
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
@@ -183,6 +184,14 @@ VALIGN_EXPORT int valign_hip_engine_create(int device, int read_length, int ref_
 }
 
 VALIGN_EXPORT void valign_hip_engine_destroy(valign_hip_engine *e) { delete e; }
+
+VALIGN_EXPORT int valign_hip_set_band_width(valign_hip_engine *e, int diagonals) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_band_width(diagonals); });
+}
 
 VALIGN_EXPORT int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy) {
     if (!e) {

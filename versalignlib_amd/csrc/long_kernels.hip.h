@@ -11,6 +11,9 @@
 //     boundary values coming in, and it drains the 64 boundary values going out -- all with
 //     coalesced 16-byte accesses.  LDS per wave is ~17 KB whatever R and F are.
 //   * The query profile is rebuilt per strip (2K byte loads per lane).
+//   * BAND (optional, Smith-Waterman): strip b sweeps only the columns
+//     [center(first row) - w, center(last row) + w], center(r) = r * F / R; every cell outside
+//     these per-strip rectangles counts as 0.  w >= max(R, F) is the unbanded computation.
 //
 // Traffic per pair: F bytes of reference per strip + 8 bytes per column and strip of boundary
 // rows; at 10k x 10k that is 0.007 B per cell -- this path stays VALU bound as well.
@@ -33,6 +36,8 @@ struct LongArgs {
     int R, F;
     int strips;                // ceil(R / (G*K))
     int row_dwords;            // dwords per boundary row: F rounded up to kPhase, plus kPhase
+    int band_half;             // < 0: every column; else strip b only sweeps the columns within band_half of
+                               // the diagonal through its rows (cells outside count as 0; SW only)
     short match, mismatch;
     short gap_read, gap_ref;
 };
@@ -45,6 +50,23 @@ struct LongLds {
     static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
     static constexpr int kTotal = kOut + geo::kGroups * kRing * 4;
 };
+
+// Columns [c_lo, c_hi] swept by strip s.  c_lo is a multiple of 4 (16-byte ring accesses).
+template <int G, int K>
+__host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows, int band_half, int &c_lo, int &c_hi) {
+    constexpr int rows = G * K;
+    if (band_half < 0 || R <= 0) {
+        c_lo = 0;
+        c_hi = F - 1;
+        return;
+    }
+    int r_lo = s * rows - pad_rows, r_hi = (s + 1) * rows - pad_rows - 1;
+    r_lo = r_lo < 0 ? 0 : r_lo;
+    r_hi = r_hi > R - 1 ? R - 1 : r_hi;
+    const long long lo = (long long)r_lo * F / R - band_half, hi = (long long)r_hi * F / R + band_half;
+    c_lo = (int)(lo < 0 ? 0 : lo) & ~3;
+    c_hi = (int)(hi > F - 1 ? F - 1 : hi);
+}
 
 template <int G, int K, int ALG, bool SYM>
 __global__ void __launch_bounds__(64)
@@ -76,7 +98,6 @@ score_long_kernel(const LongArgs args) {
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
 
     s16x2 best = pk(0), col_best = pk(0), row_best = pk(0);
-    const int steps = F + G - 1;
 
     for (int i = lane; i < geo::kPairStride / 4; i += kWave)
         reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
@@ -99,6 +120,12 @@ score_long_kernel(const LongArgs args) {
                 *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
             }
         }
+        // columns swept by this strip [c_lo, c_hi] and by the previous one [p_lo, p_hi]
+        int c_lo, c_hi, p_lo = 0, p_hi = -1;
+        strip_columns<G, K>(s, R, F, pad_rows, args.band_half, c_lo, c_hi);
+        if (s > 0) strip_columns<G, K>(s - 1, R, F, pad_rows, args.band_half, p_lo, p_hi);
+        const int ncols = c_hi - c_lo + 1;
+        const int steps = ncols + G - 1;
         const unsigned *brow_prev = args.brow + (long long)((s & 1) ^ 1) * args.pp_total * args.row_dwords;
         unsigned *brow_cur = args.brow + (long long)(s & 1) * args.pp_total * args.row_dwords;
 
@@ -106,16 +133,18 @@ score_long_kernel(const LongArgs args) {
 #pragma unroll
         for (int q = 0; q < K; ++q) Hl[q] = pk(0);
         s16x2 up0 = pk(0), h_last = pk(0);
-        int j = -l;
+        if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
+            up0 = as_pk(__builtin_nontemporal_load(brow_prev + (pp0 + grp) * args.row_dwords + (c_lo - 1)));
+        int j = c_lo - l;
 
         auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked_tag)::value;
             const s16x2 diag0 = up0;
             // row above: previous lane of the group; for the first lane the previous strip's bottom row
             const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x138, 0xF, 0xF, true);
-            const unsigned from_ring = *(lds_cu32 *)(in_base + ((t & (kRing - 1)) << 2));
+            const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
             up0 = as_pk(l == 0 ? from_ring : from_lane);
-            if (!MASKED || (unsigned)j < (unsigned)F) {
+            if (!MASKED || (unsigned)(j - c_lo) < (unsigned)ncols) {
                 const unsigned ca_addr = codes_base + ((j & (kRing - 1)) << 1);
                 const unsigned ca = *(lds_cu8 *)(ca_addr), cb = *(lds_cu8 *)(ca_addr + 1);
                 s16x2 S[K];
@@ -159,10 +188,10 @@ score_long_kernel(const LongArgs args) {
         };
 
         for (int t0 = 0; t0 < steps; t0 += kPhase) {
-            // ---- ring refill for columns [t0, t0 + kPhase) ----
+            // ---- ring refill for columns [c_lo + t0, c_lo + t0 + kPhase) ----
             {
                 // class codes: lane -> pair lane/8, eight columns
-                const int p = lane / 8, c0 = t0 + (lane % 8) * 8;
+                const int p = lane / 8, c0 = c_lo + t0 + (lane % 8) * 8;
                 const int ps = p > last ? last : p;
                 const uint8_t *src = args.refs + (pair0 + ps) * F;
                 unsigned char *dst = codes + (p / 2) * (kRing * 2) + (p & 1);
@@ -174,12 +203,16 @@ score_long_kernel(const LongArgs args) {
                         (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
                 }
                 // boundary values: lane -> group lane/16, four columns
-                const int g = lane / 16, col = t0 + (lane % 16) * 4;
+                const int g = lane / 16, col = c_lo + t0 + (lane % 16) * 4;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (s > 0) {       // L2-served load: the same addresses were read two strips ago and rewritten since
+                if (s > 0 && col + 4 <= args.row_dwords) {
+                    // L2-served load: the same addresses were read two strips ago and rewritten since
                     const u32x4 raw = __builtin_nontemporal_load(
                         reinterpret_cast<const u32x4 *>(brow_prev + (pp0 + g) * args.row_dwords + col));
-                    v = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                    v.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? raw.x : 0u;      // outside the previous strip's
+                    v.y = (col + 1 >= p_lo && col + 1 <= p_hi) ? raw.y : 0u;      // columns the row above is 0
+                    v.z = (col + 2 >= p_lo && col + 2 <= p_hi) ? raw.z : 0u;
+                    v.w = (col + 3 >= p_lo && col + 3 <= p_hi) ? raw.w : 0u;
                 }
                 *reinterpret_cast<uint4 *>(ring_in + g * kRing + (col & (kRing - 1))) = v;
                 if (t0 >= 2 * kPhase && s + 1 < args.strips) {           // drain what lane G-1 finished two phases ago
@@ -190,7 +223,7 @@ score_long_kernel(const LongArgs args) {
             }
             __syncthreads();
             const int t1 = t0 + kPhase < steps ? t0 + kPhase : steps;
-            if (t0 >= G - 1 && t1 <= F) {
+            if (t0 >= G - 1 && t1 <= ncols) {
                 for (int t = t0; t < t1; ++t) step(std::false_type{}, t);
             } else {
                 for (int t = t0; t < t1; ++t) step(std::true_type{}, t);
@@ -202,7 +235,7 @@ score_long_kernel(const LongArgs args) {
             const int phases = (steps + kPhase - 1) / kPhase;
             const int g = lane / 16;
             for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
-                const int oc = ph * kPhase + (lane % 16) * 4;
+                const int oc = c_lo + ph * kPhase + (lane % 16) * 4;
                 if (oc + 4 <= args.row_dwords)
                     *reinterpret_cast<uint4 *>(brow_cur + (pp0 + g) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
