@@ -232,6 +232,27 @@ def main():
         lin_ms = kernel_launch_ms(eng_lin, 0, reads, refs, local, 5)
         line["linear_gap"] = {"kernel_ms": round(lin_ms, 4), "kernel_gcups": round(n * R * F / (lin_ms * 1e-3) / 1e9, 1),
                               "note": "reference's own gap model (bit-exact path), same batch"}
+        # BASELINE config 3 (NW + traceback) on the same batch, device-resident: extra evidence,
+        # never part of `value`
+        try:
+            AL = R + F
+            rows = torch.empty((n, 2, AL), dtype=torch.uint8, device=device)
+            idx = torch.empty((n, 4), dtype=torch.int16, device=device)
+            line["alignments"] = {}
+            for name, e in (("nw_affine_traceback", eng), ("nw_linear_traceback", eng_lin)):
+                e.align_device(1, reads, refs, rows, idx)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e.align_device(1, reads, refs, rows, idx)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                line["alignments"][name] = {"ms": round(ms, 3), "gcups": round(n * R * F / (ms * 1e-3) / 1e9, 1),
+                                            "algorithmic_GBps": round(n * (3 * AL + 8) / (ms * 1e-3) / 1e9, 1)}
+            del rows, idx
+        except hipkernel.HipKernelError as e:
+            line["alignments"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(reads, refs, affine=True)
             line["linear_gap"]["cpu_port"] = cpu_baseline(reads, refs, affine=False)

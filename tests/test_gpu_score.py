@@ -152,3 +152,30 @@ def test_symmetric_and_asymmetric_affine_kernels(aff):
             got = hip.score_alignments(opt, reads, refs)
             exp = cpu_ref.score(opt, reads, refs, sc, threads=8, affine=True)
             assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])
+
+
+def test_int16_range_is_checked_per_call():
+    """A shape whose cells could leave int16 is refused loudly (the reference wraps silently)."""
+    R, F = 2000, 2000
+    reads, refs = _data(R, F, 4, 81)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20) as hip:     # 2000 * 20 > 32000
+        with pytest.raises(host.PluginError, match="int16 range"):
+            hip.score_alignments(0, reads, refs)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:                      # default scores fit
+        assert np.array_equal(hip.score_alignments(0, reads, refs), cpu_ref.score(0, reads, refs, threads=8))
+
+
+def test_flat_host_entry_point():
+    """valign_hip_score_host: the virtual without the C++ object (char** in, shorts out)."""
+    import ctypes
+    R, F, n = 64, 128, 777
+    reads, refs = _data(R, F, n, 82)
+    eng = hipkernel.Engine(R, F)
+    rp = (ctypes.c_void_p * n)(*[reads[i].ctypes.data for i in range(n)])
+    fp = (ctypes.c_void_p * n)(*[refs[i].ctypes.data for i in range(n)])
+    out = np.zeros(n, dtype=np.int16)
+    for opt in (0, 1):
+        rc = hipkernel.lib().valign_hip_score_host(eng._h, opt, n, rp, fp, out.ctypes.data, 4)
+        assert rc == 0
+        assert np.array_equal(out, cpu_ref.score(opt, reads, refs, threads=8))
+    eng.close()

@@ -100,3 +100,15 @@ def test_shard_ranges():
             edges = [shard.shard_range(n, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_constructor_refuses_what_the_kernels_cannot_compute():
+    """Parameter validation happens before any device is touched, so it is checkable anywhere:
+    positive gap scores (the row padding needs non-positive ones) and shapes beyond the ABI's
+    16-bit coordinates are refused with a message, never computed wrongly."""
+    with pytest.raises(host.PluginError, match="positive gap scores"):
+        host.Plugin(build.HIP_PLUGIN, 10, 10, score_gap_read=1)
+    with pytest.raises(host.PluginError, match="16-bit coordinates"):
+        host.Plugin(build.HIP_PLUGIN, 20000, 20000)
+    with pytest.raises(host.PluginError, match="outside int16"):
+        host.Plugin(build.HIP_PLUGIN, 10, 10, score_match=70000)

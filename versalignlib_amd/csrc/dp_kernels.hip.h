@@ -14,18 +14,26 @@
 //     the reference left to right in a skewed (anti-diagonal) front: at step t lane l
 //     works on reference column t - l.  The "left" dependency is a register, "up" is
 //     the previous register of the same lane, and only the last row of each lane
-//     travels to lane l+1 -- one DPP wave_shr:1 per step, no LDS traffic for DP state.
+//     travels to lane l+1 -- one DPP move per step, no LDS traffic for DP state.
 //   * Rows are padded at the TOP (rows before the read starts carry class "none",
 //     substitution 0): with non-positive gap scores those rows stay exactly at the
 //     row-0 boundary value, so the real last row is always the last register of the
 //     last lane and no per-cell row masking is needed.
-//   * Substitution scores come from a per-pair query profile in LDS (5 classes x
-//     padded rows, int16), laid out so that a lane fetches the scores of its K rows
-//     for the current reference base with ds_read_b64 / ds_read_b32; reference bases
-//     are staged once as class codes in LDS.  Inputs are raw ASCII as delivered by
-//     the ABI (1 byte per base), fetched from HBM with 16-byte coalesced loads.
-//   * Lanes outside [0, F) columns are EXEC-masked, so finished lanes keep the values
-//     of the last column (needed by the NW-variant result).
+//   * Substitution scores come from a per-pair query profile in LDS: four slabs
+//     (A, T, C, G) of padded-rows x int16 per pair plus one all-zero slab shared by every
+//     pair; the reference bases are staged once as slab numbers, so a lane's fetch address
+//     is lane_base + slab * stride and its K scores arrive with the widest ds_read the
+//     lane stride allows.  The slab stride carries the padding that a compile-time bank
+//     model (profile_conflicts) finds conflict-free.  Inputs are raw ASCII as delivered
+//     by the ABI (1 byte per base): refs via 16-byte coalesced loads, reads as coalesced
+//     byte loads.
+//   * Recurrence variants (GAPS): two linear gap scores (7 packed instructions per
+//     register = per two cells), one shared gap score (6), affine (11), affine with the
+//     same open/extend for both directions (10).  The SW maximum is tracked on diag+S,
+//     off the dependency chain.
+//   * Pipeline fill/drain steps EXEC-mask lanes outside columns [0, F) (finished lanes keep
+//     the values of the last column, needed by the NW-variant result); the steady phase
+//     runs unmasked.
 #pragma once
 
 #include <hip/hip_runtime.h>
