@@ -69,6 +69,10 @@ int vh_score(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *
 int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs,
              uint8_t *rows, int16_t *idx, int normalise);
 
+/* Wall seconds the plugin spent inside the last compute_alignments virtual call of vh_align
+ * (without the harness's own copy-out and the Alignment destructors).                         */
+double vh_last_call_seconds(vh_plugin *p);
+
 /* As vh_score / vh_align but every sequence is first copied into its own heap block
  * (what the reference host's pad() produces), so gather costs are realistic; used
  * for end-to-end timing.  seconds_out receives the wall time of the virtual call.   */

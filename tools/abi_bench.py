@@ -32,12 +32,16 @@ def main():
                               "threads": a.threads, "seconds": round(sec, 4),
                               "gcups_pcie_inclusive": round(synth.gcups(a.pairs, R, F, sec), 1)}))
         n = a.align_pairs
-        k.compute_alignments(0, reads[:blk], refs[:blk])
-        t0 = time.perf_counter()
-        k.compute_alignments(0, reads[:n], refs[:n], normalise=False)
-        sec = time.perf_counter() - t0
-        print(json.dumps({"call": "compute_alignments(SW) via ABI incl. 2n new[] rows + harness copy-out", "pairs": n,
-                          "seconds": round(sec, 4), "gcups_pcie_inclusive": round(synth.gcups(n, R, F, sec), 1)}))
+        k.compute_alignments(0, reads[:n], refs[:n], normalise=False)      # sizes the pinned staging once
+        for rep in range(2):
+            t0 = time.perf_counter()
+            k.compute_alignments(0, reads[:n], refs[:n], normalise=False)
+            sec = time.perf_counter() - t0
+        inside = k.last_call_seconds()
+        print(json.dumps({"call": "compute_alignments(SW) via ABI, 2n new[] rows", "pairs": n,
+                          "seconds_in_plugin": round(inside, 4),
+                          "gcups_pcie_inclusive": round(synth.gcups(n, R, F, inside), 1),
+                          "seconds_with_harness_copy_out": round(sec, 4)}))
 
 
 if __name__ == "__main__":

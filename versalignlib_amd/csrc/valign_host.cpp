@@ -91,6 +91,7 @@ struct vh_plugin {
     AlignmentKernel *kernel = nullptr;
     HostParameters params;
     HostLogger logger;
+    double last_call_seconds = 0.0;      // wall time of the last compute_alignments virtual call
 };
 
 namespace {
@@ -233,8 +234,10 @@ int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *
         fp[i] = (const char *)refs + (size_t)i * F;
     }
     Alignment *alns = new Alignment[(size_t)n]();     // value-initialised, as main.cpp:123
+    auto t0 = std::chrono::steady_clock::now();
     int rc = guarded("compute_alignments",
                      [&] { p->kernel->compute_alignments(opt, n, rp.data(), fp.data(), alns); });
+    p->last_call_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc == 0) {
         for (int i = 0; i < n; ++i) {
             uint8_t *rr = rows + (size_t)i * 2 * AL, *fr = rr + AL;
@@ -263,6 +266,8 @@ int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *
     delete[] alns;
     return rc;
 }
+
+double vh_last_call_seconds(vh_plugin *p) { return p ? p->last_call_seconds : 0.0; }
 
 void vh_close(vh_plugin *p) {
     if (!p) return;

@@ -39,6 +39,8 @@ def lib():
         L.vh_score_scattered.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, i16p,
                                          ctypes.POINTER(ctypes.c_double)]
         L.vh_align.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, u8p, i16p, ctypes.c_int]
+        L.vh_last_call_seconds.restype = ctypes.c_double
+        L.vh_last_call_seconds.argtypes = [vp]
         L.vh_close.restype = None
         L.vh_close.argtypes = [vp]
         L.vh_drain_log.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
@@ -145,6 +147,10 @@ class Plugin:
         if rc != 0:
             raise PluginError(_err())
         return rows, idx
+
+    def last_call_seconds(self):
+        """Wall seconds inside the plugin's last compute_alignments call."""
+        return float(lib().vh_last_call_seconds(self._h))
 
     def drain_log(self):
         buf = ctypes.create_string_buffer(1 << 16)
