@@ -21,6 +21,8 @@
  *                                                         1 SSE2/AVX2 tie-breaks (linear gaps)
  *       band_width ...................................... > 0: banded Smith-Waterman scores, that
  *                                                         many diagonals around the main one (strip band)
+ *       score_width ..................................... DP cells of score_alignments: 0 auto (int16,
+ *                                                         int32 where int16 could overflow), 16, 32
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
@@ -84,6 +86,12 @@ int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
  * outside those rectangles counts as 0.  0 (default) computes every cell; a band wider than the
  * matrix gives the unbanded result.  An extension: the reference has no banding.                 */
 int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
+
+/* DP cell width of the score path: 0 (default) = int16 like the reference, switching to int32 cells
+ * for (shape, scoring, mode) whose cells could leave int16 (the reference would wrap silently);
+ * 16 = int16 or refuse; 32 = always int32 (strip path, one pair per register: half the rate).
+ * Scores beyond the ABI's short saturate at 32767.                                               */
+int valign_hip_set_score_width(valign_hip_engine *e, int bits);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and
  * d_refs = n*ref_length bytes (raw ASCII, pair-major, NUL padded), d_scores = n int16.

@@ -590,6 +590,49 @@ int vref_score_banded_sw(int n, int R, int F, const uint8_t *reads, const uint8_
     return n;
 }
 
+/* ---- int32 cells (extension): the same two score recurrences without the reference's int16
+ * wrap-around, for (shape, scoring) whose cells leave int16; results saturate at 32767, the
+ * largest score the ABI's short can carry.                                                   */
+int vref_score_wide(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                    const vref_scoring *sc, int16_t *scores, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int gr = sc->gap_read, gf = sc->gap_ref, alg = opt & 0xF;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(prev, 0, sizeof(int32_t) * (size_t)(F + 1));
+            cur[0] = 0;
+            int32_t best = 0;
+            for (int i = 0; i < R; ++i) {
+                const int16_t *srow = tab[g_class[rd[i]]];
+                for (int j = 0; j < F; ++j) {
+                    int32_t h = prev[j] + srow[g_class[rf[j]]];
+                    if (prev[j + 1] + gf > h) h = prev[j + 1] + gf;
+                    if (cur[j] + gr > h) h = cur[j] + gr;
+                    if (alg == 0) { if (h < 0) h = 0; if (h > best) best = h; }
+                    cur[j + 1] = h;
+                }
+                if (alg == 1 && cur[F] > best) best = cur[F];
+                int32_t *t = prev; prev = cur; cur = t;
+                cur[0] = 0;
+            }
+            if (alg == 1) for (int j = 0; j <= F; ++j) if (prev[j] > best) best = prev[j];
+            scores[p] = (int16_t)(best > 32767 ? 32767 : best);
+        }
+        free(cur);
+        free(prev);
+    }
+    return n;
+}
+
 int vref_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

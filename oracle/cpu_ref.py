@@ -54,7 +54,7 @@ def lib():
         u8p = ctypes.POINTER(ctypes.c_uint8)
         i16p = ctypes.POINTER(ctypes.c_int16)
         sp = ctypes.POINTER(Scoring)
-        for name in ("vref_score", "vref_score_affine"):
+        for name in ("vref_score", "vref_score_affine", "vref_score_wide"):
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, i16p, ctypes.c_int]
@@ -80,14 +80,14 @@ def _check(reads, refs):
     return reads, refs
 
 
-def score(opt, reads, refs, scoring=None, threads=1, affine=False):
+def score(opt, reads, refs, scoring=None, threads=1, affine=False, wide=False):
     """reads [n,R] uint8, refs [n,F] uint8 -> int16 [n] (full-width scores)."""
     reads, refs = _check(reads, refs)
     sc = scoring or Scoring.make()
     n, R = reads.shape
     F = refs.shape[1]
     out = np.zeros(n, dtype=np.int16)
-    fn = lib().vref_score_affine if affine else lib().vref_score
+    fn = lib().vref_score_affine if affine else (lib().vref_score_wide if wide else lib().vref_score)
     fn(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc),
        out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
     return out

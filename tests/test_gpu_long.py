@@ -83,3 +83,37 @@ def test_config5_banded_10k():
     assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, 512, threads=8))
     full = cpu_ref.score(0, reads[:4], refs[:4], threads=8)
     assert (got[:4] <= full).all()
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 7), (400, 333, 40, 8), (2500, 700, 9, 9)])
+def test_int32_cells_forced(R, F, n, seed):
+    """score_width = 32: one pair per register, int32 cells (strip path); same results in range."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
+    for gaps in ((-3, -3), (-2, -4)):
+        sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+        with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1], score_width=32) as hip:
+            for opt in (0, 1):
+                assert np.array_equal(hip.score_alignments(opt, reads, refs), cpu_ref.score(opt, reads, refs, sc, threads=8))
+
+
+def test_int32_cells_take_over_where_int16_would_wrap():
+    """match = 20 on 2000 x 2000: cells reach 40000.  Auto mode computes them in int32 (saturating
+    the ABI's short at 32767); score_width = 16 refuses instead."""
+    R, F, n = 2000, 2000, 12
+    reads, refs = synth.make_pairs(n, R, F, seed=77, sub_rate=0.02, n_run_frac=0.0, short_frac=0.2)
+    sc = cpu_ref.Scoring.make(20, -1, -3, -3)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    exp = cpu_ref.score(0, reads, refs, sc, threads=8, wide=True)
+    assert np.array_equal(got, exp)
+    assert (exp == 32767).any() and (exp < 32767).any()
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20, score_width=16) as hip:
+        with pytest.raises(host.PluginError, match="int16 range"):
+            hip.score_alignments(0, reads, refs)
+    # NW variant on a long pair: intermediate cells dip below -32768 with gap -8
+    R, F, n = 5000, 5000, 6
+    reads, refs = synth.make_pairs(n, R, F, seed=78, sub_rate=0.3, short_frac=0.0)
+    sc = cpu_ref.Scoring.make(2, -8, -8, -8)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_mismatch=-8, score_gap_read=-8, score_gap_ref=-8) as hip:
+        got = hip.score_alignments(1, reads, refs)
+    assert np.array_equal(got, cpu_ref.score(1, reads, refs, sc, threads=8, wide=True))

@@ -155,12 +155,15 @@ def test_symmetric_and_asymmetric_affine_kernels(aff):
 
 
 def test_int16_range_is_checked_per_call():
-    """A shape whose cells could leave int16 is refused loudly (the reference wraps silently)."""
+    """A shape whose cells could leave int16 never wraps silently (as the reference would): scores
+    move to int32 cells, alignments (int16 only) are refused loudly."""
     R, F = 2000, 2000
     reads, refs = _data(R, F, 4, 81)
     with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20) as hip:     # 2000 * 20 > 32000
         with pytest.raises(host.PluginError, match="int16 range"):
-            hip.score_alignments(0, reads, refs)
+            hip.compute_alignments(0, reads, refs)
+        got = hip.score_alignments(0, reads, refs)
+        assert np.array_equal(got, cpu_ref.score(0, reads, refs, cpu_ref.Scoring.make(20, -1, -3, -3), threads=8, wide=True))
     with host.Plugin(build.HIP_PLUGIN, R, F) as hip:                      # default scores fit
         assert np.array_equal(hip.score_alignments(0, reads, refs), cpu_ref.score(0, reads, refs, threads=8))
 

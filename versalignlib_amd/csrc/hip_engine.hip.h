@@ -74,9 +74,11 @@ constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribut
 
 // Long-read path (row strips + column phases, long_kernels.hip.h): one geometry, linear gaps.
 constexpr int kLongG = 16, kLongK = 10;
-static const void *const kLongKernels[2][2] = {
-    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true>},
-    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true>}};
+static const void *const kLongKernels[2][2][2] = {     // [alg][gap_read == gap_ref][int32 cells]
+    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true>},
+     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true>}},
+    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true>},
+     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, true>}}};
 
 struct LaunchPlan {
     bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
@@ -129,6 +131,12 @@ public:
         if (diagonals > 0 && !plan_.long_mode) plan_ = long_plan();
     }
     int band_width() const { return band_width_; }
+    // DP cell width of score_alignments: 0 = int16 unless the shape could overflow it (default),
+    // 16 = int16 or refuse, 32 = always int32 (strip path, half the throughput)
+    void set_score_width(int bits) {
+        if (bits != 0 && bits != 16 && bits != 32) throw std::runtime_error("score_width must be 0, 16 or 32");
+        score_width_ = bits;
+    }
     // 0: Default/OpenCL kernel tie-breaks (default); 1: SSE2/AVX2 kernel tie-breaks
     void set_traceback_policy(int policy) {
         if (policy != 0 && policy != 1) throw std::runtime_error("traceback_policy must be 0 (default) or 1 (sse)");
@@ -144,9 +152,10 @@ public:
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;          // reference: unsupported mode is a silent no-op
         hip_check(hipSetDevice(device_), "hipSetDevice");
-        check_int16_range(alg);
-        if (plan_.long_mode) {
-            score_long_device(alg, n, d_reads, d_refs, d_scores, stream);
+        if (score_width_ == 16) check_int16_range(alg);
+        const bool wide = score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg));
+        if (plan_.long_mode || wide) {      // int32 cells exist on the strip path only
+            score_long_device(alg, n, d_reads, d_refs, d_scores, stream, wide);
             return;
         }
         ScoreArgs a;
@@ -189,14 +198,14 @@ public:
 
     // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
     void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool wide) {
         if (band_width_ > 0 && alg != kAlgSW)
             throw std::runtime_error("band_width applies to Smith-Waterman scores only");
         if (sc_.affine)
             throw std::runtime_error("the long-read path implements the linear gap model only (read_length " +
                                      std::to_string(R_) + " needs row strips)");
         const int rows = kLongG * kLongK;
-        const int ppw = plan_.pairs_per_wave;
+        const int ppw = 2 * (kWave / kLongG);
         LongArgs a;
         a.R = R_;
         a.F = F_;
@@ -207,7 +216,7 @@ public:
         a.mismatch = (short)sc_.mismatch;
         a.gap_read = (short)sc_.gap_read;
         a.gap_ref = (short)sc_.gap_ref;
-        const size_t bytes_per_wave = (size_t)2 * (ppw / 2) * a.row_dwords * 4;
+        const size_t bytes_per_wave = (size_t)2 * (ppw / 2) * a.row_dwords * 4 * (wide ? 2 : 1);
         long long chunk = (long long)((8ull << 30) / bytes_per_wave) * ppw;
         chunk = std::max<long long>(ppw, std::min(chunk, (n + ppw - 1) / ppw * ppw));
         const long long waves = chunk / ppw;
@@ -218,7 +227,8 @@ public:
             brow_bytes_ = (size_t)waves * bytes_per_wave;
             hip_check(hipMalloc((void **)&d_brow_, brow_bytes_), "hipMalloc(boundary rows)");
         }
-        const void *fn = kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0];
+        const void *fn = kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
+        const int long_lds = LongLds<kLongG, kLongK>::kTotal;
         for (long long begin = 0; begin < n; begin += chunk) {
             const long long cnt = std::min(chunk, n - begin);
             a.reads = d_reads + (size_t)begin * R_;
@@ -226,15 +236,25 @@ public:
             a.scores = d_scores + begin;
             a.brow = d_brow_;
             a.n = cnt;
-            a.pp_total = waves * (ppw / 2);
+            a.pp_total = waves * (ppw / 2) * (wide ? 2 : 1);
             void *kargs[] = {&a};
             hip_check(hipLaunchKernel(fn, dim3((unsigned)((cnt + ppw - 1) / ppw)), dim3(kWave), kargs,
-                                      (size_t)plan_.lds.total, stream),
+                                      (size_t)long_lds, stream),
                       "hipLaunchKernel(score_long_kernel)");
         }
     }
 
-    // int16 DP cells: the reference wraps silently; refuse (shape, scoring, mode) where it could.
+    // int16 DP cells: the reference wraps silently.  Scores switch to int32 cells on the strip path
+    // where they could; alignments (int16 only) are refused.
+    bool int16_range_ok(int alg) const {
+        try {
+            check_int16_range(alg);
+            return true;
+        } catch (const std::runtime_error &) {
+            return false;
+        }
+    }
+
     void check_int16_range(int alg) const {
         const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
         const int worst_gap = std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, 0});
@@ -656,6 +676,7 @@ private:
     Scoring sc_;
     bool sse_policy_ = false;
     int band_width_ = 0;
+    int score_width_ = 0;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     std::string arch_;
     LaunchPlan plan_;

@@ -68,6 +68,7 @@ public:
                                              opt_param("hip_rows_per_lane", 0)));
             engine_->set_traceback_policy(opt_param("traceback_policy", 0));
             engine_->set_band_width(opt_param("band_width", 0));
+            engine_->set_score_width(opt_param("score_width", 0));
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
@@ -191,6 +192,14 @@ VALIGN_EXPORT int valign_hip_set_band_width(valign_hip_engine *e, int diagonals)
         return 1;
     }
     return flat_guard([&] { e->impl->set_band_width(diagonals); });
+}
+
+VALIGN_EXPORT int valign_hip_set_score_width(valign_hip_engine *e, int bits) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_score_width(bits); });
 }
 
 VALIGN_EXPORT int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy) {

@@ -42,6 +42,30 @@ struct LongArgs {
     short gap_read, gap_ref;
 };
 
+// DP cell representation of the long-read kernel.  Packed: two pairs per register, int16 (the
+// reference's cell type).  Wide: one pair per register, int32 -- for (shape, scoring) whose cells
+// could leave int16; the lane group then sweeps its two pairs one after the other.
+template <bool WIDE>
+struct Cell;
+template <>
+struct Cell<false> {
+    using T = s16x2;
+    static __device__ __forceinline__ T bc(int v) { return pk((short)v); }
+    static __device__ __forceinline__ T mx(T a, T b) { return pk_max(a, b); }
+    static __device__ __forceinline__ T sub0(T a, T g) { return pk_sub_floor0(a, g); }
+    static __device__ __forceinline__ unsigned bits(T v) { return as_u32(v); }
+    static __device__ __forceinline__ T from_bits(unsigned v) { return as_pk(v); }
+};
+template <>
+struct Cell<true> {
+    using T = int;
+    static __device__ __forceinline__ T bc(int v) { return v; }
+    static __device__ __forceinline__ T mx(T a, T b) { return a > b ? a : b; }
+    static __device__ __forceinline__ T sub0(T a, T g) { const int d = a - g; return d > 0 ? d : 0; }
+    static __device__ __forceinline__ unsigned bits(T v) { return (unsigned)v; }
+    static __device__ __forceinline__ T from_bits(unsigned v) { return (int)v; }
+};
+
 template <int G, int K>
 struct LongLds {
     using geo = Geo<G, K>;
@@ -68,11 +92,13 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
     c_hi = (int)(hi > F - 1 ? F - 1 : hi);
 }
 
-template <int G, int K, int ALG, bool SYM>
+template <int G, int K, int ALG, bool SYM, bool WIDE>
 __global__ void __launch_bounds__(64)
 score_long_kernel(const LongArgs args) {
     using geo = Geo<G, K>;
     using lay = LongLds<G, K>;
+    using ops = Cell<WIDE>;
+    using cell_t = typename ops::T;
     static_assert(kPhase >= G - 1, "a phase must cover the pipeline skew");
     const int lane = threadIdx.x;
     const int grp = lane / G;
@@ -94,10 +120,13 @@ score_long_kernel(const LongArgs args) {
     unsigned *out_grp = ring_out + grp * kRing;
     const long long pp0 = pair0 / 2;                                      // first pair-of-pairs of the wave
 
-    const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
-    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
+    const cell_t g_read = ops::bc(ALG == kAlgSW ? -args.gap_read : args.gap_read);
+    const cell_t g_ref = ops::bc(ALG == kAlgSW ? -args.gap_ref : args.gap_ref);
 
-    s16x2 best = pk(0), col_best = pk(0), row_best = pk(0);
+  // wide cells: the group's two pairs take turns (half 0, then half 1); packed cells: one pass
+  for (int half = 0; half < (WIDE ? 2 : 1); ++half) {
+    cell_t best = ops::bc(0), col_best = ops::bc(0), row_best = ops::bc(0);
+    const long long brow_slot = WIDE ? (pp0 + grp) * 2 + half : (pp0 + grp);   // boundary row of this sweep
 
     for (int i = lane; i < geo::kPairStride / 4; i += kWave)
         reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
@@ -129,59 +158,69 @@ score_long_kernel(const LongArgs args) {
         const unsigned *brow_prev = args.brow + (long long)((s & 1) ^ 1) * args.pp_total * args.row_dwords;
         unsigned *brow_cur = args.brow + (long long)(s & 1) * args.pp_total * args.row_dwords;
 
-        s16x2 Hl[K];
+        cell_t Hl[K];
 #pragma unroll
-        for (int q = 0; q < K; ++q) Hl[q] = pk(0);
-        s16x2 up0 = pk(0), h_last = pk(0);
+        for (int q = 0; q < K; ++q) Hl[q] = ops::bc(0);
+        cell_t up0 = ops::bc(0), h_last = ops::bc(0);
         if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
-            up0 = as_pk(__builtin_nontemporal_load(brow_prev + (pp0 + grp) * args.row_dwords + (c_lo - 1)));
+            up0 = ops::from_bits(__builtin_nontemporal_load(brow_prev + brow_slot * args.row_dwords + (c_lo - 1)));
         int j = c_lo - l;
 
         auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-            const s16x2 diag0 = up0;
+            const cell_t diag0 = up0;
             // row above: previous lane of the group; for the first lane the previous strip's bottom row
-            const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x138, 0xF, 0xF, true);
+            const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
             const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
-            up0 = as_pk(l == 0 ? from_ring : from_lane);
+            up0 = ops::from_bits(l == 0 ? from_ring : from_lane);
             if (!MASKED || (unsigned)(j - c_lo) < (unsigned)ncols) {
                 const unsigned ca_addr = codes_base + ((j & (kRing - 1)) << 1);
                 const unsigned ca = *(lds_cu8 *)(ca_addr), cb = *(lds_cu8 *)(ca_addr + 1);
-                s16x2 S[K];
-                fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
-                s16x2 d[K];
+                cell_t S[K];
+                if constexpr (WIDE) {
+                    unsigned raw[K / 2];
+                    lds_load_lane<K>(lane_base + (half ? cb : ca) * geo::kPairStride, raw);
+#pragma unroll
+                    for (int c = 0; c < K / 2; ++c) {
+                        S[2 * c] = (int)(short)(raw[c] & 0xFFFFu);
+                        S[2 * c + 1] = (int)raw[c] >> 16;
+                    }
+                } else {
+                    fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+                }
+                cell_t d[K];
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                    if (ALG == kAlgSW) best = pk_max(best, d[q]);
+                    if (ALG == kAlgSW) best = ops::mx(best, d[q]);
                 }
-                s16x2 h = up0;
+                cell_t h = up0;
                 if (SYM) {
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
-                        const s16x2 x = pk_max(Hl[q], h);
-                        const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
-                        h = pk_max(d[q], y);
+                        const cell_t x = ops::mx(Hl[q], h);
+                        const cell_t y = (ALG == kAlgSW) ? ops::sub0(x, g_ref) : x + g_ref;
+                        h = ops::mx(d[q], y);
                         Hl[q] = h;
                     }
                 } else {
-                    s16x2 m[K];
+                    cell_t m[K];
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
-                        const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
-                        m[q] = pk_max(d[q], e);
+                        const cell_t e = (ALG == kAlgSW) ? ops::sub0(Hl[q], g_read) : Hl[q] + g_read;
+                        m[q] = ops::mx(d[q], e);
                     }
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
-                        const s16x2 f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
-                        h = pk_max(m[q], f);
+                        const cell_t f = (ALG == kAlgSW) ? ops::sub0(h, g_ref) : h + g_ref;
+                        h = ops::mx(m[q], f);
                         Hl[q] = h;
                     }
                 }
                 h_last = h;
                 if (l == G - 1) {
-                    out_grp[j & (kRing - 1)] = as_u32(h);                  // bottom row of the strip
-                    if (ALG == kAlgNW) row_best = pk_max(row_best, h);
+                    out_grp[j & (kRing - 1)] = ops::bits(h);               // bottom row of the strip
+                    if (ALG == kAlgNW) row_best = ops::mx(row_best, h);
                 }
             }
             ++j;
@@ -208,7 +247,7 @@ score_long_kernel(const LongArgs args) {
                 if (s > 0 && col + 4 <= args.row_dwords) {
                     // L2-served load: the same addresses were read two strips ago and rewritten since
                     const u32x4 raw = __builtin_nontemporal_load(
-                        reinterpret_cast<const u32x4 *>(brow_prev + (pp0 + g) * args.row_dwords + col));
+                        reinterpret_cast<const u32x4 *>(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + col));
                     v.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? raw.x : 0u;      // outside the previous strip's
                     v.y = (col + 1 >= p_lo && col + 1 <= p_hi) ? raw.y : 0u;      // columns the row above is 0
                     v.z = (col + 2 >= p_lo && col + 2 <= p_hi) ? raw.z : 0u;
@@ -217,7 +256,7 @@ score_long_kernel(const LongArgs args) {
                 *reinterpret_cast<uint4 *>(ring_in + g * kRing + (col & (kRing - 1))) = v;
                 if (t0 >= 2 * kPhase && s + 1 < args.strips) {           // drain what lane G-1 finished two phases ago
                     const int oc = col - 2 * kPhase;
-                    *reinterpret_cast<uint4 *>(brow_cur + (pp0 + g) * args.row_dwords + oc) =
+                    *reinterpret_cast<uint4 *>(brow_cur + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
                 }
             }
@@ -237,32 +276,38 @@ score_long_kernel(const LongArgs args) {
             for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
                 const int oc = c_lo + ph * kPhase + (lane % 16) * 4;
                 if (oc + 4 <= args.row_dwords)
-                    *reinterpret_cast<uint4 *>(brow_cur + (pp0 + g) * args.row_dwords + oc) =
+                    *reinterpret_cast<uint4 *>(brow_cur + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
             }
         }
         if (ALG == kAlgNW) {                    // every lane froze at the last column: this strip's rows
 #pragma unroll
-            for (int q = 0; q < K; ++q) col_best = pk_max(col_best, Hl[q]);
-            if (s + 1 < args.strips) row_best = pk(0);     // only the last strip holds the last row
+            for (int q = 0; q < K; ++q) col_best = ops::mx(col_best, Hl[q]);
+            if (s + 1 < args.strips) row_best = ops::bc(0);  // only the last strip holds the last row
         }
     }
 
-    s16x2 res;
+    cell_t res;
     if (ALG == kAlgSW) {
         res = best;
     } else {
-        res = pk_max(col_best, l == G - 1 ? row_best : pk(0));
-        res = pk_max(res, pk(0));
+        res = ops::mx(col_best, l == G - 1 ? row_best : ops::bc(0));
+        res = ops::mx(res, ops::bc(0));
     }
 #pragma unroll
     for (int dd = G / 2; dd >= 1; dd >>= 1)
-        res = pk_max(res, as_pk((unsigned)__shfl_xor((int)as_u32(res), dd, kWave)));
+        res = ops::mx(res, ops::from_bits((unsigned)__shfl_xor((int)ops::bits(res), dd, kWave)));
     if (l == 0) {
         const long long pa = pair0 + 2 * grp;
-        if (pa < args.n) args.scores[pa] = res.x;
-        if (pa + 1 < args.n) args.scores[pa + 1] = res.y;
+        if constexpr (WIDE) {             // the ABI's score is a short: saturate what it cannot carry
+            const int v = res > 32767 ? 32767 : res;
+            if (pa + half < args.n) args.scores[pa + half] = (int16_t)v;
+        } else {
+            if (pa < args.n) args.scores[pa] = res.x;
+            if (pa + 1 < args.n) args.scores[pa + 1] = res.y;
+        }
     }
+  }
 }
 
 }  // namespace valign
