@@ -117,3 +117,14 @@ def test_int32_cells_take_over_where_int16_would_wrap():
     with host.Plugin(build.HIP_PLUGIN, R, F, score_mismatch=-8, score_gap_read=-8, score_gap_ref=-8) as hip:
         got = hip.score_alignments(1, reads, refs)
     assert np.array_equal(got, cpu_ref.score(1, reads, refs, sc, threads=8, wide=True))
+
+
+def test_largest_shape_the_abi_allows():
+    """read_length + ref_length = 32767 (the Alignment struct's coordinates are shorts)."""
+    R, F, n = 16383, 16384, 3
+    reads, refs = synth.make_pairs(n, R, F, seed=99, sub_rate=0.2, n_run_frac=0.0, short_frac=0.34)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    assert np.array_equal(got, cpu_ref.score(0, reads, refs, threads=8, wide=True))
+    with pytest.raises(host.PluginError, match="16-bit coordinates"):
+        host.Plugin(build.HIP_PLUGIN, R + 1, F)
