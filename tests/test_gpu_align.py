@@ -210,3 +210,25 @@ def test_sse_policy_live_against_sse_and_avx_kernels():
             got = hip.compute_alignments(opt, reads, refs)
             _assert_same(got, s.compute_alignments(opt, reads, refs), ("sse", opt))
             _assert_same(got, a.compute_alignments(opt, reads, refs), ("avx", opt))
+
+
+def test_host_paths_with_several_chunks():
+    """The host-pointer pipeline (gather -> pinned -> H2D -> kernels -> D2H -> scatter) with batches
+    that span several staging chunks, against the device-resident entry points and the oracle."""
+    import torch
+    R, F, blk = 150, 500, 8192
+    r0, f0 = synth.make_pairs(blk, R, F, seed=71, indel_rate=0.01, n_run_frac=0.02, short_frac=0.02)
+    n = 300000
+    reps = -(-n // blk)
+    reads = np.tile(r0, (reps, 1))[:n]
+    refs = np.tile(f0, (reps, 1))[:n]
+    exp_scores = cpu_ref.score(0, r0, f0, threads=8)
+    exp_rows, exp_idx = cpu_ref.align(1, r0, f0, threads=8)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=8) as hip:
+        scores = hip.score_alignments(0, reads, refs)                       # 4 chunks of ~77k pairs
+        rows, idx = hip.compute_alignments(1, reads, refs, normalise=False)  # 3 chunks of ~137k pairs
+    for k in range(reps):
+        lo, hi = k * blk, min(n, (k + 1) * blk)
+        assert np.array_equal(scores[lo:hi], exp_scores[:hi - lo]), k
+        assert np.array_equal(idx[lo:hi], exp_idx[:hi - lo]), k
+        assert np.array_equal(rows[lo:hi], exp_rows[:hi - lo]), k
