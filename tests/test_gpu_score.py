@@ -182,3 +182,19 @@ def test_flat_host_entry_point():
         assert rc == 0
         assert np.array_equal(out, cpu_ref.score(opt, reads, refs, threads=8))
     eng.close()
+
+
+def test_ragged_batches_skip_trailing_padding_exactly():
+    """Smith-Waterman kernels do not sweep the trailing columns in which no reference of a wave has an
+    ACGT base (NUL padding of ragged batches, N tails): scores and alignments must not change."""
+    R, F, n = 150, 500, 1024
+    reads, refs = synth.make_pairs(n, R, F, seed=88, indel_rate=0.01, n_run_frac=0.02, short_frac=0.0)
+    keep = 150 + (np.arange(n) * 37) % 300                      # true reference lengths 150..449
+    for i in range(n):
+        refs[i, keep[i]:] = 0 if i % 3 else ord("N")              # NUL padding or an N tail
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        assert np.array_equal(hip.score_alignments(0, reads, refs), cpu_ref.score(0, reads, refs, threads=8))
+        assert np.array_equal(hip.score_alignments(1, reads, refs), cpu_ref.score(1, reads, refs, threads=8))
+        rows, idx = hip.compute_alignments(0, reads, refs, normalise=False)
+        erows, eidx = cpu_ref.align(0, reads, refs, threads=8)
+        assert np.array_equal(idx, eidx) and np.array_equal(rows, erows)

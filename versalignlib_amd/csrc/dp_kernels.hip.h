@@ -190,6 +190,7 @@ struct WaveTables {
     int *first_bad;         // [pairs][2]: first read / ref position whose class is 0 (else R / F)
     long long pair0;        // first pair of this wave
     int last;               // index of the last existing pair of the wave (tail waves are short)
+    int cols_used;          // 1 + last column where any pair of the wave has an ACGT base (wave-uniform)
 };
 
 // Stage the wave's raw refs with coalesced 16-byte loads, then build the per-column slab
@@ -241,6 +242,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
 
     // ---- reference bases -> profile slab of the pair (class * kPairs + pair, or the zero slab) ----
+    int cols_used = 0;
     if (live) {
         for (int idx = lane; idx < geo::kGroups * F; idx += kWave) {
             const int g = idx / F, j = idx - g * F;
@@ -252,6 +254,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             unsigned char *dst = refc + g * refc_stride + 2 * j;
             dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab);
             dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab);
+            if ((ca >= 1 && ca <= 4) || (cb >= 1 && cb <= 4)) cols_used = j + 1 > cols_used ? j + 1 : cols_used;
             if (FIND_BAD) {
                 // "invalid" for the NW end cell: class 0 (Default kernel) or anything but ACGT (SSE kernel)
                 if (ca == 0 || (bad_is_non_acgt && ca == 5)) atomicMin(&first_bad[2 * (2 * g) + 1], j);
@@ -282,6 +285,12 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = 0u;
     }
     __syncthreads();
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) {
+        const int other = __shfl_xor(cols_used, d, kWave);
+        cols_used = other > cols_used ? other : cols_used;
+    }
+    w.cols_used = __builtin_amdgcn_readfirstlane(cols_used);
     w.prof = prof;
     w.refc = refc;
     w.first_bad = first_bad;
@@ -355,13 +364,16 @@ score_kernel(const ScoreArgs args) {
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
     const int l = lane % G;
-    const int F = args.F;
 
     WaveTables w;
-    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, args.R, F, args.prof_area, args.refc_stride,
+    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, args.R, args.F, args.prof_area, args.refc_stride,
                                  args.wave_lds, args.match, args.mismatch, w))
         return;
     const long long pair0 = w.pair0;
+    // Smith-Waterman: columns after the last ACGT base of every reference in the wave (the NUL
+    // padding of ragged batches) score nothing and can never raise the maximum -- not swept.
+    // The NW variant's result lives in the last column and row of the PADDED matrix: full sweep.
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
     // ---- per-lane constants (LDS byte offsets) ----
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;            // group leader: row-0 border

@@ -122,13 +122,16 @@ align_fill_kernel(const FillArgs args) {
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
     const int l = lane % G;
-    const int R = args.R, F = args.F;
+    const int R = args.R;
     const int pad_rows = geo::kRows - R;
 
     WaveTables w;
-    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
                                 args.wave_lds, args.match, args.mismatch, w))
         return;
+    // SW: the trailing columns where no reference of the wave has an ACGT base are not swept (they
+    // cannot hold the first maximum and no traceback enters them); NW variant: every column.
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
     const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
@@ -260,7 +263,7 @@ align_fill_kernel(const FillArgs args) {
         code_addr += 2;
     };
 
-    const int steps = args.blocks8 * 8;
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;   // whole 8-step blocks
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
