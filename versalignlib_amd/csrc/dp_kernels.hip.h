@@ -50,6 +50,7 @@ constexpr int kWave = 64;
 constexpr int kWaveLanes = 64;
 constexpr int kAlgSW = 0;
 constexpr int kAlgNW = 1;
+constexpr int kCodePad = 72;          // columns of zero-slab codes before column 0 and after column F-1
 constexpr short kNegInf = -16384;   // "minus infinity" of the affine NW borders (oracle: NEG_INF)
 
 struct ScoreArgs {
@@ -244,6 +245,13 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     // ---- reference bases -> profile slab of the pair (class * kPairs + pair, or the zero slab) ----
     int cols_used = 0;
     if (live) {
+        // the sweep prefetches the codes of the next columns unconditionally: pad both ends
+        for (int idx = lane; idx < geo::kGroups * 2 * kCodePad; idx += kWave) {
+            const int g = idx / (2 * kCodePad), x = idx - g * (2 * kCodePad);
+            const int col = x < kCodePad ? x : F + x;                    // [0, pad) and [F + pad, F + 2 pad)
+            unsigned char *dst = refc + g * refc_stride + 2 * col;
+            dst[0] = dst[1] = (unsigned char)geo::kZeroSlab;
+        }
         for (int idx = lane; idx < geo::kGroups * F; idx += kWave) {
             const int g = idx / F, j = idx - g * F;
             int pa = 2 * g, pb = 2 * g + 1;
@@ -251,7 +259,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             pb = pb > last ? last : pb;
             const int ca = base_class(prof[ref_skew + pa * F + j]);
             const int cb = base_class(prof[ref_skew + pb * F + j]);
-            unsigned char *dst = refc + g * refc_stride + 2 * j;
+            unsigned char *dst = refc + g * refc_stride + 2 * (j + kCodePad);
             dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab);
             dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab);
             if ((ca >= 1 && ca <= 4) || (cb >= 1 && cb <= 4)) cols_used = j + 1 > cols_used ? j + 1 : cols_used;
@@ -292,7 +300,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     }
     w.cols_used = __builtin_amdgcn_readfirstlane(cols_used);
     w.prof = prof;
-    w.refc = refc;
+    w.refc = refc + 2 * kCodePad;          // entry of column 0
     w.first_bad = first_bad;
     w.pair0 = pair0;
     w.last = last;
@@ -333,6 +341,16 @@ __device__ __forceinline__ void lds_load_lane(unsigned addr, unsigned (&v)[K / 2
     }
 }
 
+// S[q] (q = 0..K-1) from the raw profile dwords of pair A (low halves) and pair B (high halves)
+template <int K>
+__device__ __forceinline__ void merge_profile(const unsigned (&va)[K / 2], const unsigned (&vb)[K / 2], s16x2 (&S)[K]) {
+#pragma unroll
+    for (int c = 0; c < K / 2; ++c) {
+        S[2 * c + 0] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x05040100u));
+        S[2 * c + 1] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x07060302u));
+    }
+}
+
 // S[q] (q = 0..K-1): substitution scores of this lane's K rows against the current reference
 // bases of pair A (low halves) and pair B (high halves), from the LDS profile.
 template <int G, int K>
@@ -340,11 +358,7 @@ __device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, 
     unsigned va[K / 2], vb[K / 2];
     lds_load_lane<K>(addr_a, va);
     lds_load_lane<K>(addr_b, vb);
-#pragma unroll
-    for (int c = 0; c < K / 2; ++c) {
-        S[2 * c + 0] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x05040100u));
-        S[2 * c + 1] = as_pk(__builtin_amdgcn_perm(vb[c], va[c], 0x07060302u));
-    }
+    merge_profile<K>(va, vb, S);
 }
 
 // GAPS selects the recurrence: kGapLinear (two gap scores), kGapSym (linear with
@@ -406,6 +420,22 @@ score_kernel(const ScoreArgs args) {
     s16x2 up0 = pk(0), h_last = pk(0), f_last = border_f, best = pk(0), row_best = pk(0);
     int j = -l;                                                  // this lane's column at step t
 
+    // Linear-gap kernels: LDS fetches run one step ahead of the arithmetic (every lane, every step:
+    // the code arrays are padded): on entry to step t the raw profile dwords of step t and the slab
+    // numbers of step t+1 are already in registers, so no step waits for its own LDS round trips
+    // (+3 % at 16x10, +12 % at one wave per SIMD).  The affine kernels' steps are long enough to
+    // hide them behind the other wave of the SIMD; there the extra register copies cost more.
+    constexpr bool PIPE = !AFFINE;
+    unsigned pa[K / 2], pb[K / 2];
+    unsigned ca_next = 0, cb_next = 0;
+    if (PIPE) {
+        const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 2);
+        cb_next = *(lds_cu8 *)(code_addr + 3);
+    }
+
     // One step of the skewed sweep.  MASKED steps EXEC-mask lanes whose column is outside
     // [0, F) (pipeline fill and drain); in the steady phase every lane is inside.
     auto step = [&](auto masked_tag) __attribute__((always_inline)) {
@@ -421,12 +451,19 @@ score_kernel(const ScoreArgs args) {
             const unsigned fv = from_prev_lane(as_u32(f_last));
             fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
         }
+        s16x2 S[K];
+        if (PIPE) {
+            merge_profile<K>(pa, pb, S);                                     // step t's scores
+            lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows
+            lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+            ca_next = *(lds_cu8 *)(code_addr + 4);                            // step t+2's slab numbers
+            cb_next = *(lds_cu8 *)(code_addr + 5);
+        }
         if (!MASKED || (unsigned)j < (unsigned)F) {
-            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
-            const unsigned addr_a = lane_base + ca * geo::kPairStride;
-            const unsigned addr_b = lane_base + cb * geo::kPairStride;
-            s16x2 S[K];
-            fetch_profile<G, K>(addr_a, addr_b, S);
+            if (!PIPE) {
+                const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+                fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            }
             if (SYM) {
                 // h = max(diag + S, max(left, up) - g): one subtract for both gap directions
                 s16x2 d[K];
@@ -542,7 +579,7 @@ inline WaveLds wave_lds(int R, int F) {
     const int raw_refs = ((geo::kPairs * F + 16 + 15) / 16) * 16;    // staged raw, then overwritten
     w.prof_area = geo::kProfBytes > raw_refs ? geo::kProfBytes : raw_refs;
     w.prof_area = ((w.prof_area + 15) / 16) * 16;
-    w.refc_stride = ((2 * F + 15) / 16) * 16;
+    w.refc_stride = ((2 * (F + 2 * kCodePad) + 15) / 16) * 16;
     w.total = w.prof_area + geo::kGroups * w.refc_stride + ((geo::kPairs * 8 + 15) / 16) * 16;
     return w;
 }
