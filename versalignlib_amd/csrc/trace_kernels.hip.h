@@ -231,13 +231,13 @@ align_fill_kernel(const FillArgs args) {
                 Hl[q] = h;
                 // back pointer: 0 if h == diag + S, else 1 if it came from above, else 2
                 const s16x2 nd = pk_min_u(h - d[q], one);
-                code[q] = pk_mad_u(nd, nu, nd);
+                code[q] = (s16x2)((u16x2)nd << (u16x2)nu);        // nd * (1 + nu): 0 DIAG, 1 UP, 2 LEFT
                 if (ALG == kAlgSW) {
-                    // per-row first arg-max (strictly greater wins, so the first column is kept)
-                    const s16x2 nb = pk_max(rb[q], h);
-                    const s16x2 changed = (rb[q] - nb) >> fifteen;   // 0xFFFF where the row best rose
+                    // per-row first arg-max (strictly greater wins, so the first column is kept);
+                    // SW cells are >= 0, so rb - h cannot wrap
+                    const s16x2 changed = (rb[q] - h) >> fifteen;    // 0xFFFF where h beats the row best
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
-                    rb[q] = nb;
+                    rb[q] = pk_max(rb[q], h);
                 } else {
                     hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
                 }
@@ -386,13 +386,12 @@ align_fill_affine_kernel(const FillArgs args) {
                 Hl[q] = h;
                 const s16x2 nd = pk_min_u(h - d[q], one);
                 const s16x2 nf = pk_min_u(h - f, one);
-                code_h[q] = pk_mad_u(nd, nf, nd);                 // 0 DIAG, 1 from F, 2 from E
+                code_h[q] = (s16x2)((u16x2)nd << (u16x2)nf);      // nd * (1 + nf): 0 DIAG, 1 from F, 2 from E
                 code_g[q] = pk_mad_u(code_g[q], two, pk_min_u(f - f_open, one));   // bit1 E extended, bit0 F extended
                 if (ALG == kAlgSW) {
-                    const s16x2 nb = pk_max(rb[q], h);
-                    const s16x2 changed = (rb[q] - nb) >> fifteen;
+                    const s16x2 changed = (rb[q] - h) >> fifteen;
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
-                    rb[q] = nb;
+                    rb[q] = pk_max(rb[q], h);
                 } else {
                     hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
                 }
@@ -542,10 +541,9 @@ align_fill_sse_kernel(const FillArgs args) {
                 const s16x2 t1 = pk_mad_u(nl, nu, nl);
                 code[q] = three - pk_mad_u(ndv, t1, ndv);          // 3 DIAG, 2 LEFT, 1 UP, 0 START
                 if (ALG == kAlgSW) {
-                    const s16x2 nb = pk_max(rb[q], h);
-                    const s16x2 changed = (rb[q] - nb) >> fifteen;
+                    const s16x2 changed = (rb[q] - h) >> fifteen;
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
-                    rb[q] = nb;
+                    rb[q] = pk_max(rb[q], h);
                 } else {
                     hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
                 }
