@@ -214,6 +214,24 @@ align_fill_kernel(const FillArgs args) {
             }
             s16x2 h = up0;
             s16x2 hs = pk(0);
+            // The chain down the column (max, sub, max per row) is strictly dependent; the pointer and
+            // arg-max arithmetic of the PREVIOUS row is written between its links so that every
+            // dependent pair of packed instructions has independent work in between.
+            s16x2 nu_prev = pk(0), h_prev = pk(0);
+            auto finish_row = [&](int q, s16x2 hq, s16x2 nuq) __attribute__((always_inline)) {
+                // back pointer: 0 if h == diag + S, else 1 if it came from above, else 2
+                const s16x2 nd = pk_min_u(hq - d[q], one);
+                code[q] = (s16x2)((u16x2)nd << (u16x2)nuq);       // nd * (1 + nu): 0 DIAG, 1 UP, 2 LEFT
+                if (ALG == kAlgSW) {
+                    // per-row first arg-max (strictly greater wins, so the first column is kept);
+                    // SW cells are >= 0, so rb - h cannot wrap
+                    const s16x2 changed = (rb[q] - hq) >> fifteen;   // 0xFFFF where h beats the row best
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = pk_max(rb[q], hq);
+                } else {
+                    hs = as_pk((as_u32(sel[q]) & as_u32(hq)) | (~as_u32(sel[q]) & as_u32(hs)));
+                }
+            };
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 s16x2 nu;
@@ -222,26 +240,19 @@ align_fill_kernel(const FillArgs args) {
                     const s16x2 x = pk_max(Hl[q], h);
                     nu = pk_min_u(x - h, one);
                     const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
+                    if (q > 0) finish_row(q - 1, h_prev, nu_prev);
                     h = pk_max(d[q], y);
                 } else {
                     const s16x2 ug = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                    if (q > 0) finish_row(q - 1, h_prev, nu_prev);
                     h = pk_max(m[q], ug);
                     nu = pk_min_u(h - ug, one);
                 }
                 Hl[q] = h;
-                // back pointer: 0 if h == diag + S, else 1 if it came from above, else 2
-                const s16x2 nd = pk_min_u(h - d[q], one);
-                code[q] = (s16x2)((u16x2)nd << (u16x2)nu);        // nd * (1 + nu): 0 DIAG, 1 UP, 2 LEFT
-                if (ALG == kAlgSW) {
-                    // per-row first arg-max (strictly greater wins, so the first column is kept);
-                    // SW cells are >= 0, so rb - h cannot wrap
-                    const s16x2 changed = (rb[q] - h) >> fifteen;    // 0xFFFF where h beats the row best
-                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
-                    rb[q] = pk_max(rb[q], h);
-                } else {
-                    hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
-                }
+                h_prev = h;
+                nu_prev = nu;
             }
+            finish_row(K - 1, h_prev, nu_prev);
             if (ALG == kAlgNW) {
                 const s16x2 nb = pk_max(rb[0], hs);
                 const s16x2 changed = (rb[0] - nb) >> fifteen;
