@@ -420,12 +420,11 @@ score_kernel(const ScoreArgs args) {
     s16x2 up0 = pk(0), h_last = pk(0), f_last = border_f, best = pk(0), row_best = pk(0);
     int j = -l;                                                  // this lane's column at step t
 
-    // Linear-gap kernels: LDS fetches run one step ahead of the arithmetic (every lane, every step:
-    // the code arrays are padded): on entry to step t the raw profile dwords of step t and the slab
-    // numbers of step t+1 are already in registers, so no step waits for its own LDS round trips
-    // (+3 % at 16x10, +12 % at one wave per SIMD).  The affine kernels' steps are long enough to
-    // hide them behind the other wave of the SIMD; there the extra register copies cost more.
-    constexpr bool PIPE = !AFFINE;
+    // LDS fetches run one step ahead of the arithmetic (every lane, every step: the code arrays are
+    // padded): on entry to step t the raw profile dwords of step t and the slab numbers of step t+1
+    // are already in registers, so no step waits for its own LDS round trips (+3 % at 16x10, +12 %
+    // at one wave per SIMD).
+    constexpr bool PIPE = true;
     unsigned pa[K / 2], pb[K / 2];
     unsigned ca_next = 0, cb_next = 0;
     if (PIPE) {
@@ -537,9 +536,9 @@ score_kernel(const ScoreArgs args) {
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
     for (; t < fill_end; ++t) step(std::true_type{});
-    if (!AFFINE) {                             // two steps per trip: loop-carried registers swap roles
-        for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW; the longer
-            step(std::false_type{});           // affine step gains nothing)
+    {                                          // two steps per trip: loop-carried registers swap roles
+        for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW linear,
+            step(std::false_type{});           // +4 % affine together with the pipelined fetch)
             step(std::false_type{});
         }
     }
