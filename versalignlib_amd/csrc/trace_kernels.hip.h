@@ -279,6 +279,10 @@ align_fill_kernel(const FillArgs args) {
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
     for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t + 1 < steady_end; t += 2) {       // two steps per trip (loop-carried registers swap roles)
+        step(std::false_type{}, t);
+        step(std::false_type{}, t + 1);
+    }
     for (; t < steady_end; ++t) step(std::false_type{}, t);
     for (; t < steps; ++t) step(std::true_type{}, t);
 
@@ -437,6 +441,10 @@ align_fill_affine_kernel(const FillArgs args) {
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
     for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t + 1 < steady_end; t += 2) {       // two steps per trip (loop-carried registers swap roles)
+        step(std::false_type{}, t);
+        step(std::false_type{}, t + 1);
+    }
     for (; t < steady_end; ++t) step(std::false_type{}, t);
     for (; t < steps; ++t) step(std::true_type{}, t);
 
@@ -583,6 +591,10 @@ align_fill_sse_kernel(const FillArgs args) {
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
     for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t + 1 < steady_end; t += 2) {       // two steps per trip (loop-carried registers swap roles)
+        step(std::false_type{}, t);
+        step(std::false_type{}, t + 1);
+    }
     for (; t < steady_end; ++t) step(std::false_type{}, t);
     for (; t < steps; ++t) step(std::true_type{}, t);
 
