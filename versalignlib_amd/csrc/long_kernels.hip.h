@@ -263,7 +263,12 @@ score_long_kernel(const LongArgs args) {
             __syncthreads();
             const int t1 = t0 + kPhase < steps ? t0 + kPhase : steps;
             if (t0 >= G - 1 && t1 <= ncols) {
-                for (int t = t0; t < t1; ++t) step(std::false_type{}, t);
+                int t = t0;
+                for (; t + 1 < t1; t += 2) {        // two steps per trip (loop-carried registers swap roles)
+                    step(std::false_type{}, t);
+                    step(std::false_type{}, t + 1);
+                }
+                for (; t < t1; ++t) step(std::false_type{}, t);
             } else {
                 for (int t = t0; t < t1; ++t) step(std::true_type{}, t);
             }
