@@ -93,3 +93,38 @@ def test_cli_with_hip_kernel(tmp_path):
     out, stdout = _run_cli(build.HIP_PLUGIN, tmp_path)
     _check_outputs(out, reads, refs, full_scores=True)
     assert stdout.splitlines()[0] == "Threads\t1\t2"
+
+
+def _ref_host():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_host")
+    return path if os.path.exists(path) else None
+
+
+def _run_ref_host(kernel, tmp_path):
+    out = tmp_path / "refout"
+    out.mkdir(exist_ok=True)
+    res = subprocess.run([_ref_host(), kernel, str(tmp_path / "reads.fa"), str(tmp_path / "refs.fa"), str(out), "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return out
+
+
+def test_reference_host_code_drives_the_reference_kernel(tmp_path):
+    """oracle/_ref/ref_host is built from the reference's OWN host code (its headers, DLL_init, pad,
+    FastaProvider); sanity: with the reference Default kernel it writes what the oracle predicts."""
+    default = ref_kernel("Default")
+    if not default or not _ref_host():
+        pytest.skip("oracle/_ref not built")
+    reads, refs = _batch(tmp_path)
+    _check_outputs(_run_ref_host(default, tmp_path), reads, refs, full_scores=False)
+
+
+@pytest.mark.gpu
+def test_reference_host_code_drives_the_hip_plugin(tmp_path):
+    """The drop-in claim, end to end: a host compiled against the reference's headers (not this
+    repo's restatement of them) dlopen()s libHIPKernel.so through the reference's DLL_init and gets
+    the oracle's scores and alignments."""
+    if not _ref_host():
+        pytest.skip("oracle/_ref not built")
+    reads, refs = _batch(tmp_path, n=200, R=150, F=500, seed=19)
+    _check_outputs(_run_ref_host(build.HIP_PLUGIN, tmp_path), reads, refs, full_scores=True)
