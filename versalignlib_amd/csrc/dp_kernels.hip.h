@@ -368,6 +368,8 @@ constexpr int kGapSym = 1;
 constexpr int kGapAffine = 2;
 constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_read == ext_ref
 
+constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
+
 template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
@@ -437,8 +439,14 @@ score_kernel(const ScoreArgs args) {
 
     // One step of the skewed sweep.  MASKED steps EXEC-mask lanes whose column is outside
     // [0, F) (pipeline fill and drain); in the steady phase every lane is inside.
-    auto step = [&](auto masked_tag) __attribute__((always_inline)) {
+    // TRACK selects how a step feeds the running SW maximum: kTrackAll = every diag+S of the step;
+    // in the steady phase of the shared-gap kernel steps go in pairs -- the first adds nothing
+    // (kTrackNone), the second adds every max(left, up) plus its last row (kTrackPair): the "left"s
+    // are all cells of the first step, the "up"s all cells of the second but the last row.  K + 1
+    // maxima per two steps instead of 2K.
+    auto step = [&](auto masked_tag, auto track_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int TRACK = decltype(track_tag)::value;
         const s16x2 diag0 = up0;
         if (G == 16) {             // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
@@ -469,16 +477,19 @@ score_kernel(const ScoreArgs args) {
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                    if (ALG == kAlgSW) best = pk_max(best, d[q]);   // the maximum is always a diagonal arrival
+                    if (ALG == kAlgSW && TRACK == kTrackAll)
+                        best = pk_max(best, d[q]);               // the maximum is always a diagonal arrival
                 }
                 s16x2 h = up0;
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     const s16x2 x = pk_max(Hl[q], h);
+                    if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, x);
                     const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
                     h = pk_max(d[q], y);
                     Hl[q] = h;
                 }
+                if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, h);
                 h_last = h;
             } else {
                 // pass 1: everything that only needs the previous column
@@ -535,15 +546,18 @@ score_kernel(const ScoreArgs args) {
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
-    for (; t < fill_end; ++t) step(std::true_type{});
+    using all_t = std::integral_constant<int, kTrackAll>;
+    using first_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackNone : kTrackAll>;
+    using second_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackPair : kTrackAll>;
+    for (; t < fill_end; ++t) step(std::true_type{}, all_t{});
     {                                          // two steps per trip: loop-carried registers swap roles
         for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW linear,
-            step(std::false_type{});           // +4 % affine together with the pipelined fetch)
-            step(std::false_type{});
+            step(std::false_type{}, first_t{});    // +4 % affine together with the pipelined fetch)
+            step(std::false_type{}, second_t{});
         }
     }
-    for (; t < steady_end; ++t) step(std::false_type{});
-    for (; t < steps; ++t) step(std::true_type{});
+    for (; t < steady_end; ++t) step(std::false_type{}, all_t{});
+    for (; t < steps; ++t) step(std::true_type{}, all_t{});
 
     // ---- result ----
     s16x2 res;
