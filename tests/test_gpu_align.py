@@ -232,3 +232,24 @@ def test_host_paths_with_several_chunks():
         assert np.array_equal(scores[lo:hi], exp_scores[:hi - lo]), k
         assert np.array_equal(idx[lo:hi], exp_idx[:hi - lo]), k
         assert np.array_equal(rows[lo:hi], exp_rows[:hi - lo]), k
+
+
+def test_full_size_properties_config3():
+    """BASELINE config 3 at full size (1M pairs, 150 x 500, NW affine + traceback): the batch is 256
+    copies of a 4096-pair block, so rows and coordinates must repeat with that period (checked on
+    the device), and the first block must equal the oracle."""
+    import torch
+    R, F, blk, reps = 150, 500, 4096, 256
+    reads, refs = synth.make_pairs(blk, R, F, seed=52, indel_rate=0.01)
+    aff = (-5, -1, -5, -1)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
+    d_reads = torch.from_numpy(reads).cuda().repeat(reps, 1).contiguous()
+    d_refs = torch.from_numpy(refs).cuda().repeat(reps, 1).contiguous()
+    rows, idx = eng.align_device(1, d_reads, d_refs)
+    torch.cuda.synchronize()
+    rows = rows.view(reps, blk, 2, R + F)
+    idx = idx.view(reps, blk, 4)
+    assert bool((rows == rows[0:1]).all()) and bool((idx == idx[0:1]).all())
+    erows, eidx = cpu_ref.align(1, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3, *aff), threads=8, affine=True)
+    assert np.array_equal(idx[0].cpu().numpy(), eidx) and np.array_equal(rows[0].cpu().numpy(), erows)
+    eng.close()
