@@ -472,22 +472,23 @@ score_kernel(const ScoreArgs args) {
                 fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             }
             if (SYM) {
-                // h = max(diag + S, max(left, up) - g): one subtract for both gap directions
-                s16x2 d[K];
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                    if (ALG == kAlgSW && TRACK == kTrackAll)
-                        best = pk_max(best, d[q]);               // the maximum is always a diagonal arrival
-                }
+                // h = max(diag + S, max(left, up) - g): one subtract for both gap directions.  The chain
+                // max -> sub -> max down the column is strictly dependent; the next row's diag + S (which
+                // reads the OLD left value just before it is overwritten) and the maximum tracking are
+                // written between its links so that no two dependent packed instructions are adjacent.
                 s16x2 h = up0;
+                s16x2 d_cur = diag0 + S[0];
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     const s16x2 x = pk_max(Hl[q], h);
-                    if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, x);
+                    s16x2 d_next = pk(0);
+                    if (q + 1 < K) d_next = Hl[q] + S[q + 1];
                     const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
-                    h = pk_max(d[q], y);
+                    if (ALG == kAlgSW && TRACK == kTrackAll) best = pk_max(best, d_cur);   // max = a diagonal arrival
+                    if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, x);
+                    h = pk_max(d_cur, y);
                     Hl[q] = h;
+                    d_cur = d_next;
                 }
                 if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, h);
                 h_last = h;
