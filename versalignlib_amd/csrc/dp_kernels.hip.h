@@ -493,10 +493,11 @@ score_kernel(const ScoreArgs args) {
                 if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, h);
                 h_last = h;
             } else {
-                // pass 1: everything that only needs the previous column
-                s16x2 m[K];
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
+                // Everything of a row that only needs the previous column ("pass 1": diag + S, E, their
+                // maximum, the SW maximum tracking) is computed one row ahead and written between the
+                // links of the dependent chain down the column (F and H), so that no two dependent
+                // packed instructions are adjacent.  pass1(q) reads the OLD Hl[q-1] / Hl[q] / HOl[q].
+                auto pass1 = [&](int q) __attribute__((always_inline)) -> s16x2 {
                     const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
                     s16x2 e;
                     if (AFFSYM) {
@@ -510,13 +511,13 @@ score_kernel(const ScoreArgs args) {
                     } else {
                         e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
                     }
-                    m[q] = pk_max(d, e);
                     if (ALG == kAlgSW) best = pk_max(best, d);
-                }
-                // pass 2: the in-lane chain down the column
+                    return pk_max(d, e);
+                };
                 s16x2 h = up0, f = fup0;
                 s16x2 ho = pk(0);
                 if (AFFSYM) ho = (ALG == kAlgSW) ? pk_sub_floor0(up0, o_ref) : pk_add_sat(up0, o_ref);
+                s16x2 m_cur = pass1(0);
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     if (AFFSYM) {
@@ -527,12 +528,15 @@ score_kernel(const ScoreArgs args) {
                     } else {
                         f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
                     }
-                    h = pk_max(m[q], f);
+                    s16x2 m_next = pk(0);
+                    if (q + 1 < K) m_next = pass1(q + 1);        // before Hl[q] is overwritten
+                    h = pk_max(m_cur, f);
                     Hl[q] = h;
                     if (AFFSYM) {
                         ho = (ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref);
                         HOl[q] = ho;
                     }
+                    m_cur = m_next;
                 }
                 h_last = h;
                 f_last = f;
