@@ -188,33 +188,38 @@ score_long_kernel(const LongArgs args) {
                 } else {
                     fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
                 }
-                cell_t d[K];
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                    if (ALG == kAlgSW) best = ops::mx(best, d[q]);
-                }
+                // column-independent work of row q+1 sits between the links of the dependent chain of
+                // row q (see score_kernel)
                 cell_t h = up0;
                 if (SYM) {
+                    cell_t d_cur = diag0 + S[0];
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
                         const cell_t x = ops::mx(Hl[q], h);
+                        cell_t d_next = ops::bc(0);
+                        if (q + 1 < K) d_next = Hl[q] + S[q + 1];
                         const cell_t y = (ALG == kAlgSW) ? ops::sub0(x, g_ref) : x + g_ref;
-                        h = ops::mx(d[q], y);
+                        if (ALG == kAlgSW) best = ops::mx(best, d_cur);
+                        h = ops::mx(d_cur, y);
                         Hl[q] = h;
+                        d_cur = d_next;
                     }
                 } else {
-                    cell_t m[K];
-#pragma unroll
-                    for (int q = 0; q < K; ++q) {
+                    auto pass1 = [&](int q) __attribute__((always_inline)) -> cell_t {
+                        const cell_t d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
                         const cell_t e = (ALG == kAlgSW) ? ops::sub0(Hl[q], g_read) : Hl[q] + g_read;
-                        m[q] = ops::mx(d[q], e);
-                    }
+                        if (ALG == kAlgSW) best = ops::mx(best, d);
+                        return ops::mx(d, e);
+                    };
+                    cell_t m_cur = pass1(0);
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
                         const cell_t f = (ALG == kAlgSW) ? ops::sub0(h, g_ref) : h + g_ref;
-                        h = ops::mx(m[q], f);
+                        cell_t m_next = ops::bc(0);
+                        if (q + 1 < K) m_next = pass1(q + 1);
+                        h = ops::mx(m_cur, f);
                         Hl[q] = h;
+                        m_cur = m_next;
                     }
                 }
                 h_last = h;
