@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-end measurement batch (run on the GPU box through gpurun): PMC passes, bench line,
+# kernel-trace stats of bench.py and of the alignment path, geometry sweeps, host-ABI rates.
+# Usage: tools/final_batch.sh <tag>
+set -u
+TAG=$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+bash tools/pmc_passes.sh $TAG --modes sw_affine,sw_linear,nw_linear || exit 1
+python tools/pmc_summary.py $OUT/pmc_$TAG > $OUT/pmc_${TAG}_summary.json || exit 1
+cp $OUT/pmc_${TAG}_summary.json $R/profiles/r01_pmc_final.json
+python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
+echo "bench done"
+export TMPDIR=/tmp
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $OUT/prof_$TAG.log 2>&1) || exit 1
+echo "bench trace done"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_align_$TAG -- python3 $R/tools/align_bench.py --iters 2 > $OUT/prof_align_$TAG.log 2>&1) || exit 1
+echo "align trace done"
+python tools/align_bench.py --iters 3 > $OUT/align_$TAG.log 2>&1 || exit 1
+{ python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 ;
+  python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 --affine 1 ; } > $OUT/geom_$TAG.log 2>&1 || exit 1
+echo "sweeps done"
+python tools/abi_bench.py --pairs 1048576 --align-pairs 262144 --threads 32 > $OUT/abi_$TAG.log 2>&1 || exit 1
+echo "abi done"
