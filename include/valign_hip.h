@@ -23,6 +23,10 @@
  *                                                         many diagonals around the main one (strip band)
  *       score_width ..................................... DP cells of score_alignments: 0 auto (int16,
  *                                                         int32 where int16 could overflow), 16, 32
+ *       ragged_batching ................................. length-sorted Smith-Waterman score calls
+ *                                                         (trailing non-ACGT padding is not swept,
+ *                                                         identical scores): 0 never, 1 when a sample
+ *                                                         of the call is ragged enough (default), 2 always
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
@@ -92,6 +96,15 @@ int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
  * 16 = int16 or refuse; 32 = always int32 (strip path, one pair per register: half the rate).
  * Scores beyond the ABI's short saturate at 32767.                                               */
 int valign_hip_set_score_width(valign_hip_engine *e, int bits);
+
+/* Length-sorted batching of valign_hip_score_host / score_alignments for Smith-Waterman: the
+ * reference host pads every sequence to the longest (src/util/versalignUtil.cpp:17-33) and every
+ * backend sweeps the padding; here pairs are binned by their length without trailing non-ACGT
+ * bytes and each bin is swept at its own shape.  Scores are identical (trailing padding cannot
+ * raise a Smith-Waterman maximum).  Sorting costs the host one more pass over the sequence tails,
+ * so mode 1 (default) only sorts a call whose sampled pairs would skip a third of the cells;
+ * 0 = never, 2 = always.                                                                          */
+int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and
  * d_refs = n*ref_length bytes (raw ASCII, pair-major, NUL padded), d_scores = n int16.

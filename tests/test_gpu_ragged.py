@@ -1,0 +1,108 @@
+"""Length-sorted batching: Smith-Waterman score calls that arrive with ragged,
+NUL-padded sequences are binned by trimmed length and swept at the bin's shape.  The scores must be
+exactly those of the padded sweep -- checked against the oracle and against the same library with the
+feature switched off -- and the engine must report that it swept fewer cells."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from versalignlib_amd import build, hipkernel, host, synth
+
+from conftest import ref_kernel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def small_bins(monkeypatch):
+    monkeypatch.setenv("VALIGN_HIP_RAGGED_MIN", "64")      # read at engine creation: many bins at test sizes
+
+
+CASES = [
+    # (R, F, n, seed, threads)
+    (150, 500, 20000, 41, 8),
+    (150, 500, 5000, 42, 1),
+    (64, 128, 3000, 43, 4),
+    (250, 300, 4099, 44, 3),
+    (33, 70, 2500, 45, 2),
+]
+
+
+@pytest.mark.parametrize("R,F,n,seed,threads", CASES)
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_ragged_scores_match_oracle(small_bins, R, F, n, seed, threads, gaps):
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=seed, n_run_frac=0.03, short_frac=0.02, junk_frac=0.02)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    exp = cpu_ref.score(host.SW, reads, refs, sc, threads=8)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, gaps[0], gaps[1]))
+    eng.set_ragged_batching(2)
+    got = eng.score_host(host.SW, reads, refs, threads=threads)
+    info = eng.describe(host.SW, n)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:8]
+    assert info["ragged_batching"] == 2 and info["ragged_launches"] > 1
+    assert info["ragged_cell_fraction"] < (0.75 if R >= 64 else 1.0)     # tiny shapes have two classes per side
+    eng.set_ragged_batching(0)
+    plain = eng.score_host(host.SW, reads, refs, threads=threads)
+    assert np.array_equal(plain, exp)
+    assert eng.describe(host.SW, n)["ragged_launches"] == 0
+    eng.close()
+
+
+def test_ragged_affine_and_nw_untouched(small_bins):
+    R, F, n = 150, 500, 6000
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=46)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
+    hsc = hipkernel.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
+    eng = hipkernel.Engine(R, F, hsc)
+    got = eng.score_host(host.SW, reads, refs, threads=4)
+    assert eng.describe()["ragged_launches"] > 1
+    assert np.array_equal(got, cpu_ref.score(host.SW, reads, refs, sc, threads=8, affine=True))
+    # the Needleman-Wunsch variant reads its result off the padded last row / column: never trimmed
+    got = eng.score_host(host.NW, reads, refs, threads=4)
+    assert eng.describe()["ragged_launches"] == 0
+    assert np.array_equal(got, cpu_ref.score(host.NW, reads, refs, sc, threads=8, affine=True))
+    eng.close()
+
+
+def test_ragged_through_plugin_against_reference_sse(small_bins):
+    """The plugin protocol end to end, checked against the reference's own SSE kernel (full scores)."""
+    sse = ref_kernel("SSE")
+    if not sse:
+        pytest.skip("oracle/_ref not built")
+    R, F, n = 150, 500, 4000
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=47)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as hip, host.Plugin(sse, R, F) as s, \
+            host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, ragged_batching=0) as off:
+        exp = s.score_alignments(host.SW, reads, refs)
+        assert np.array_equal(hip.score_alignments(host.SW, reads, refs), exp)
+        assert np.array_equal(off.score_alignments(host.SW, reads, refs), exp)
+        assert '"ragged_batching": 0' in off.drain_log()
+
+
+def test_uniform_batch_is_one_launch():
+    """Full-length pairs: left alone by default; forced, one bin and one launch per chunk."""
+    R, F, n = 150, 500, 3000
+    reads, refs = synth.make_pairs(n, R, F, seed=48, n_run_frac=0.0, short_frac=0.0)
+    exp = cpu_ref.score(host.SW, reads, refs, threads=8)
+    eng = hipkernel.Engine(R, F)
+    got = eng.score_host(host.SW, reads, refs, threads=2)
+    assert eng.describe()["ragged_launches"] == 0          # default mode: the sample says nothing to skip
+    assert np.array_equal(got, exp)
+    eng.set_ragged_batching(2)
+    got = eng.score_host(host.SW, reads, refs, threads=2)
+    assert eng.describe()["ragged_launches"] == 1
+    assert np.array_equal(got, exp)
+    with pytest.raises(hipkernel.HipKernelError):
+        eng.set_ragged_batching(3)
+    eng.close()
+
+
+def test_all_empty_sequences():
+    R, F, n = 64, 128, 500
+    reads = np.zeros((n, R), dtype=np.uint8)
+    refs = np.zeros((n, F), dtype=np.uint8)
+    eng = hipkernel.Engine(R, F)
+    assert not eng.score_host(host.SW, reads, refs).any()
+    eng.close()

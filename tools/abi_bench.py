@@ -18,12 +18,27 @@ def main():
     ap.add_argument("--pairs", type=int, default=1 << 18)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--align-pairs", type=int, default=1 << 16)
+    ap.add_argument("--ragged", action="store_true",
+                    help="mixed-length, NUL-padded sequences; times score_alignments with length-sorted "
+                         "batching on and off (GCUPS counted on the padded shape, as the reference does)")
     a = ap.parse_args()
     R, F = 150, 500
     blk = 4096
     r0, f0 = synth.make_pairs(blk, R, F, seed=3)
     reads = np.tile(r0, (a.pairs // blk, 1))
     refs = np.tile(f0, (a.pairs // blk, 1))
+    if a.ragged:
+        r0, f0 = synth.make_ragged_pairs(blk, R, F, seed=3)
+        reads = np.tile(r0, (a.pairs // blk, 1))
+        refs = np.tile(f0, (a.pairs // blk, 1))
+        for on in (1, 0):
+            with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=a.threads, ragged_batching=on) as k:
+                k.score_alignments(0, reads, refs, scattered=True)
+                best = min(k.score_alignments(0, reads, refs, scattered=True)[1] for _ in range(3))
+                print(json.dumps({"call": "score_alignments(SW) via ABI, ragged input", "ragged_batching": on,
+                                  "pairs": a.pairs, "threads": a.threads, "seconds": round(best, 4),
+                                  "padded_gcups_pcie_inclusive": round(synth.gcups(a.pairs, R, F, best), 1)}))
+        return
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=a.threads) as k:
         k.score_alignments(0, reads[:blk], refs[:blk])
         for rep in range(3):

@@ -53,6 +53,8 @@ constexpr int kAlgNW = 1;
 constexpr int kCodePad = 72;          // columns of zero-slab codes before column 0 and after column F-1
 constexpr short kNegInf = -16384;   // "minus infinity" of the affine NW borders (oracle: NEG_INF)
 
+constexpr int kMaxScoreGroups = 16;
+
 struct ScoreArgs {
     const uint8_t *reads;     // n * R bytes, pair-major
     const uint8_t *refs;      // n * F bytes, pair-major
@@ -65,6 +67,18 @@ struct ScoreArgs {
     short match, mismatch;
     short gap_read, gap_ref;                       // linear model, all <= 0
     short open_read, ext_read, open_ref, ext_ref;  // affine extension, all <= 0
+    // Length-sorted batches (hip_engine.hip.h, gather_ragged): one launch sweeps several packed groups
+    // of pairs that share the read stride R but have their own reference stride.  Blocks
+    // [groups[g-1].block_end, groups[g].block_end) belong to group g; reads / refs / scores / n / F
+    // above are then ignored in favour of the group's.  n_groups == 0: one plain batch.
+    int n_groups;
+    struct Group {
+        unsigned block_end;
+        int F;
+        long long n;
+        long long pair_ofs;         // into scores
+        long long read_ofs, ref_ofs;   // bytes into reads / refs
+    } groups[kMaxScoreGroups];
 };
 
 // ---- packed int16 helpers (each is one VOP3P instruction on gfx950) ----
@@ -201,7 +215,8 @@ struct WaveTables {
 template <int G, int K, bool FIND_BAD>
 __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
                                            int prof_area, int refc_stride, int wave_lds, short match,
-                                           short mismatch, WaveTables &w, bool bad_is_non_acgt = false) {
+                                           short mismatch, WaveTables &w, bool bad_is_non_acgt = false,
+                                           unsigned block = blockIdx.x) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -213,7 +228,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
     int *first_bad = reinterpret_cast<int *>(refc + geo::kGroups * refc_stride);
 
     const int waves = blockDim.x / kWave;
-    const long long pair0 = ((long long)blockIdx.x * waves + wave) * geo::kPairs;
+    const long long pair0 = ((long long)block * waves + wave) * geo::kPairs;
     const bool live = pair0 < n;
     long long pair_end = pair0 + geo::kPairs;
     if (pair_end > n) pair_end = n;
@@ -381,15 +396,32 @@ score_kernel(const ScoreArgs args) {
     const int grp = lane / G;
     const int l = lane % G;
 
+    // the batch (or, in a length-sorted launch, the group this block belongs to): wave-uniform
+    const uint8_t *reads = args.reads, *refs = args.refs;
+    int16_t *scores = args.scores;
+    long long n_pairs = args.n;
+    int F_batch = args.F;
+    unsigned block = blockIdx.x;
+    if (args.n_groups > 0) {
+        int g = 0;
+        while (g + 1 < args.n_groups && block >= args.groups[g].block_end) ++g;
+        block -= g ? args.groups[g - 1].block_end : 0u;
+        reads += args.groups[g].read_ofs;
+        refs += args.groups[g].ref_ofs;
+        scores += args.groups[g].pair_ofs;
+        n_pairs = args.groups[g].n;
+        F_batch = args.groups[g].F;
+    }
+
     WaveTables w;
-    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, args.R, args.F, args.prof_area, args.refc_stride,
-                                 args.wave_lds, args.match, args.mismatch, w))
+    if (!wave_setup<G, K, false>(reads, refs, n_pairs, args.R, F_batch, args.prof_area, args.refc_stride,
+                                 args.wave_lds, args.match, args.mismatch, w, false, block))
         return;
     const long long pair0 = w.pair0;
     // Smith-Waterman: columns after the last ACGT base of every reference in the wave (the NUL
     // padding of ragged batches) score nothing and can never raise the maximum -- not swept.
     // The NW variant's result lives in the last column and row of the PADDED matrix: full sweep.
-    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+    const int F = (ALG == kAlgSW) ? w.cols_used : F_batch;
 
     // ---- per-lane constants (LDS byte offsets) ----
     const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;            // group leader: row-0 border
@@ -581,11 +613,11 @@ score_kernel(const ScoreArgs args) {
         res = pk_max(res, as_pk((unsigned)__shfl_xor((int)as_u32(res), d, kWave)));
     if (l == 0) {
         const long long pa = pair0 + 2 * grp;
-        if (pa + 1 < args.n && ((unsigned long long)args.scores & 3ull) == 0) {
-            *reinterpret_cast<unsigned *>(args.scores + pa) = as_u32(res);
+        if (pa + 1 < n_pairs && ((unsigned long long)scores & 3ull) == 0) {
+            *reinterpret_cast<unsigned *>(scores + pa) = as_u32(res);
         } else {
-            if (pa < args.n) args.scores[pa] = res.x;
-            if (pa + 1 < args.n) args.scores[pa + 1] = res.y;
+            if (pa < n_pairs) scores[pa] = res.x;
+            if (pa + 1 < n_pairs) scores[pa + 1] = res.y;
         }
     }
 }

@@ -12,6 +12,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -70,6 +77,7 @@ static const Geometry kGeometries[] = {
 constexpr int kNumGeometries = sizeof(kGeometries) / sizeof(kGeometries[0]);
 
 constexpr int kMaxBlockLds = 160 * 1024;       // gfx950: 160 KiB per CU, one block may take it all
+constexpr int kSlots = 4;                      // staging slots of the host-pointer pipeline
 constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribute must be raised
 
 // Long-read path (row strips + column phases, long_kernels.hip.h): one geometry, linear gaps.
@@ -88,8 +96,102 @@ struct LaunchPlan {
     int pairs_per_wave = 0;
 };
 
+// Host worker threads that outlive a call: gather / scatter run on them chunk after chunk (spawning
+// num_threads std::threads per chunk cost as much as the copying itself).  run(parts, fn) calls
+// fn(part) for every part in [0, parts) on the workers and the calling thread and returns when all
+// are done; an exception from fn is rethrown on the caller.
+class WorkerPool {
+public:
+    explicit WorkerPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    int workers() const { return (int)threads_.size(); }
+
+    void run(int parts, const std::function<void(int)> &fn) {
+        if (parts <= 0) return;
+        if (parts == 1 || threads_.empty()) {
+            for (int p = 0; p < parts; ++p) fn(p);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_ = &fn;
+            parts_ = parts;
+            next_.store(0);
+            left_ = parts;
+            error_ = nullptr;
+            generation_.fetch_add(1, std::memory_order_release);
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this] { return left_ == 0; });
+        job_ = nullptr;
+        if (error_) std::rethrow_exception(error_);
+    }
+
+private:
+    void work() {
+        for (;;) {
+            const int p = next_.fetch_add(1);
+            if (p >= parts_) return;
+            std::exception_ptr err;
+            try {
+                (*job_)(p);
+            } catch (...) {
+                err = std::current_exception();
+            }
+            std::lock_guard<std::mutex> lock(m_);
+            if (err && !error_) error_ = err;
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                wake_.wait(lock, [&] { return stop_.load() || generation_.load() != seen; });
+                if (stop_.load()) return;
+                seen = generation_.load();
+            }
+            work();
+        }
+    }
+
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int parts_ = 0, left_ = 0;
+    std::atomic<unsigned long long> generation_{0};
+    std::atomic<bool> stop_{false};
+    std::exception_ptr error_;
+};
+
 class Engine {
 public:
+    struct LengthGroup {
+        int R = 0, F = 0;               // strides (= swept shape) of the group
+        long long pairs = 0, pair_ofs = 0;
+        size_t read_ofs = 0, ref_ofs = 0;
+    };
+    struct RaggedStats {             // of the last score_host call
+        int launches = 0;
+        double cells_swept = 0, cells_padded = 0;
+        double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
+        double classify_ms = 0;                              // part of gather_ms: trimmed lengths + binning
+    };
+
     Engine(int device, int R, int F, const Scoring &sc, int force_g, int force_k)
         : device_(device), R_(R), F_(F), sc_(sc) {
         if (R < 0 || F < 0) throw std::runtime_error("negative sequence length");
@@ -107,9 +209,12 @@ public:
         arch_ = prop.gcnArchName;
         if (arch_.find("gfx950") == std::string::npos)
             throw std::runtime_error("device is " + arch_ + "; this library carries gfx950 code only");
-        plan_ = choose_plan(force_g, force_k);
-        for (int s = 0; s < 2; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
-        for (int s = 0; s < 2; ++s) hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
+        force_g_ = force_g;
+        force_k_ = force_k;
+        plan_ = choose_plan(R_, F_, force_g, force_k);
+        build_length_classes();
+        for (int s = 0; s < kSlots; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
+        for (int s = 0; s < kSlots; ++s) hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
     }
 
     ~Engine() {
@@ -117,7 +222,7 @@ public:
         release_staging();
         release_trace_scratch();
         if (d_brow_) (void)hipFree(d_brow_);
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < kSlots; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
             if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
         }
@@ -142,6 +247,13 @@ public:
         if (policy != 0 && policy != 1) throw std::runtime_error("traceback_policy must be 0 (default) or 1 (sse)");
         sse_policy_ = policy == 1;
     }
+    // Length-sorted batching of Smith-Waterman score calls that arrive as host pointers:
+    // 0 = never (every pair is swept at read_length x ref_length), 1 = when a sample of the call's
+    // pairs says it would skip a third of the cells (default), 2 = always
+    void set_ragged_batching(int mode) {
+        if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
+        ragged_ = mode;
+    }
     int device() const { return device_; }
     const LaunchPlan &plan() const { return plan_; }
     hipStream_t own_stream() const { return streams_[0]; }
@@ -158,16 +270,43 @@ public:
             score_long_device(alg, n, d_reads, d_refs, d_scores, stream, wide);
             return;
         }
+        launch_score(plan_, alg, R_, F_, n, d_reads, d_refs, d_scores, stream);
+    }
+
+    // One launch of the register-sweep score kernel over n pairs of shape R x F (sequences laid
+    // out pair-major at exactly those strides) with the geometry of `plan`.
+    // `groups` (length-sorted batches): packed groups sharing the read stride R, each with its own
+    // reference stride <= F, swept by one launch; offsets are relative to d_reads / d_refs / d_scores.
+    void launch_score(const LaunchPlan &plan, int alg, int R, int F, long long n, const uint8_t *d_reads,
+                      const uint8_t *d_refs, int16_t *d_scores, hipStream_t stream,
+                      const LengthGroup *groups = nullptr, int n_groups = 0) {
         ScoreArgs a;
         a.reads = d_reads;
         a.refs = d_refs;
         a.scores = d_scores;
         a.n = n;
-        a.R = R_;
-        a.F = F_;
-        a.prof_area = plan_.lds.prof_area;
-        a.refc_stride = plan_.lds.refc_stride;
-        a.wave_lds = plan_.lds.total;
+        a.R = R;
+        a.F = F;
+        a.n_groups = n_groups;
+        const long long pairs_per_block = (long long)plan.pairs_per_wave * plan.waves_per_block;
+        long long blocks = (n + pairs_per_block - 1) / pairs_per_block;
+        if (n_groups > 0) {
+            if (n_groups > kMaxScoreGroups) throw std::runtime_error("too many length groups for one launch");
+            blocks = 0;
+            for (int g = 0; g < n_groups; ++g) {
+                blocks += (groups[g].pairs + pairs_per_block - 1) / pairs_per_block;
+                if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
+                a.groups[g].block_end = (unsigned)blocks;
+                a.groups[g].F = groups[g].F;
+                a.groups[g].n = groups[g].pairs;
+                a.groups[g].pair_ofs = groups[g].pair_ofs;
+                a.groups[g].read_ofs = (long long)groups[g].read_ofs;
+                a.groups[g].ref_ofs = (long long)groups[g].ref_ofs;
+            }
+        }
+        a.prof_area = plan.lds.prof_area;
+        a.refc_stride = plan.lds.refc_stride;
+        a.wave_lds = plan.lds.total;
         a.match = (short)sc_.match;
         a.mismatch = (short)sc_.mismatch;
         a.gap_read = (short)sc_.gap_read;
@@ -181,16 +320,15 @@ public:
             gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
         else
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
-        const void *fn = plan_.geo->kernel[alg][gaps];
-        const int block_lds = plan_.lds.total * plan_.waves_per_block;
+        const void *fn = plan.geo->kernel[alg][gaps];
+        const int block_lds = plan.lds.total * plan.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        const long long pairs_per_block = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        const long long blocks = (n + pairs_per_block - 1) / pairs_per_block;
         if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
+        if (blocks == 0) return;
         void *kargs[] = {&a};
-        hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), kargs,
+        hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan.waves_per_block * kWave), kargs,
                                   (size_t)block_lds, stream),
                   "hipLaunchKernel(score_kernel)");
     }
@@ -266,8 +404,18 @@ public:
                                      std::to_string(R_) + ", ref_length " + std::to_string(F_) + ")");
     }
 
-    // Host pointers in, host scores out.  Chunked: while chunk c runs on the device the
-    // host threads gather chunk c+1 into the other pinned slot.
+    // Host pointers in, host scores out.  Chunked over kSlots pinned slots, each with its own
+    // stream: while the kernel of chunk c runs, chunk c+1 crosses PCIe and the host threads gather
+    // chunk c+2 (two slots would serialise copy and kernel of a chunk behind the gather).
+    //
+    // Smith-Waterman chunks are length-sorted on the way (the reference pads
+    // every sequence to the longest, src/util/versalignUtil.cpp:17-33, and sweeps the padding):
+    // trailing bytes that are not ACGT score 0 against everything (DefaultKernel.h:83-97), so with
+    // gap scores <= 0 no cell of a trailing row or column can exceed the maximum already seen and
+    // the SW score of the trimmed pair is the score of the padded one.  Pairs are binned by trimmed
+    // (read, ref) length class, each bin is packed at its own strides and swept by the geometry
+    // that suits it; scores return through the permutation.  Bit-exact by construction, checked in
+    // tests/test_gpu_ragged.py.
     void score_host(int opt, int n, const char *const *reads, const char *const *refs, short *scores,
                     int threads) {
         const int alg = opt & 0xF;
@@ -280,30 +428,75 @@ public:
         ensure_staging(chunk);
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
-        int slot = 0;
-        for (long long begin = 0; begin < n; begin += chunk, slot ^= 1) {
-            const long long cnt = std::min<long long>(chunk, n - begin);
-            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
-            if (slot_pending_[slot] > 0) {         // drain the result of the chunk that used this slot
-                memcpy(scores + slot_begin_[slot], h_scores_[slot], sizeof(short) * (size_t)slot_pending_[slot]);
-                slot_pending_[slot] = 0;
+        const bool ragged = ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
+        const bool shared_scratch = plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg);
+        ragged_stats_ = RaggedStats{};
+        auto drain = [&](int s) {
+            if (slot_pending_[s] <= 0) return;
+            short *dst = scores + slot_begin_[s];
+            if (slot_ragged_[s]) {
+                const int *pos = pos_[s].data();
+                for (long long i = 0; i < slot_pending_[s]; ++i) dst[i] = h_scores_[s][pos[i]];
+            } else {
+                memcpy(dst, h_scores_[s], sizeof(short) * (size_t)slot_pending_[s]);
             }
-            gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
-            hipStream_t st = streams_[slot];
-            hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
-            hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
-            score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+            slot_pending_[s] = 0;
+        };
+        int slot = 0;
+        for (long long begin = 0; begin < n; begin += chunk, slot = (slot + 1) % kSlots) {
+            const long long cnt = std::min<long long>(chunk, n - begin);
+            auto t0 = std::chrono::steady_clock::now();
+            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
+            auto t1 = std::chrono::steady_clock::now();
+            drain(slot);                            // the result of the chunk that used this slot
+            auto t2 = std::chrono::steady_clock::now();
+            ragged_stats_.wait_ms += ms_between(t0, t1);
+            ragged_stats_.drain_ms += ms_between(t1, t2);
+            // kernels that share a scratch (strip boundary rows) stay on one stream
+            hipStream_t st = streams_[shared_scratch ? 0 : slot];
+            if (ragged) {
+                const std::vector<LengthGroup> groups = gather_ragged(reads + begin, refs + begin, cnt, slot, threads);
+                ragged_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
+                size_t read_bytes = 0, ref_bytes = 0;
+                for (const LengthGroup &g : groups) {
+                    read_bytes = std::max(read_bytes, g.read_ofs + (size_t)g.pairs * g.R);
+                    ref_bytes = std::max(ref_bytes, g.ref_ofs + (size_t)g.pairs * g.F);
+                }
+                hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], read_bytes, hipMemcpyHostToDevice, st), "H2D reads");
+                hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], ref_bytes, hipMemcpyHostToDevice, st), "H2D refs");
+                // one launch per read class: its reference-length groups ride in the kernel's group table
+                for (size_t first = 0; first < groups.size();) {
+                    size_t end = first;
+                    int widest = 0;
+                    while (end < groups.size() && groups[end].R == groups[first].R) widest = std::max(widest, groups[end++].F);
+                    launch_score(class_plan(groups[first].R, widest), alg, groups[first].R, widest, 0, d_reads_[slot],
+                                 d_refs_[slot], d_scores_[slot], st, groups.data() + first, (int)(end - first));
+                    ragged_stats_.launches += 1;
+                    first = end;
+                }
+                for (const LengthGroup &g : groups) ragged_stats_.cells_swept += (double)g.pairs * g.R * g.F;
+                ragged_stats_.cells_padded += (double)cnt * R_ * F_;
+            } else {
+                gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
+                ragged_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
+                hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
+                hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
+                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+            }
             hip_check(hipMemcpyAsync(h_scores_[slot], d_scores_[slot], sizeof(short) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H scores");
             hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;
+            slot_ragged_[slot] = ragged;
         }
-        for (int s = 0; s < 2; ++s) {
+        for (int k = 0; k < kSlots; ++k) {          // oldest chunk first
+            const int s = (slot + k) % kSlots;
+            auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
-            if (slot_pending_[s] > 0) {
-                memcpy(scores + slot_begin_[s], h_scores_[s], sizeof(short) * (size_t)slot_pending_[s]);
-                slot_pending_[s] = 0;
-            }
+            auto t1 = std::chrono::steady_clock::now();
+            drain(s);
+            ragged_stats_.wait_ms += ms_between(t0, t1);
+            ragged_stats_.drain_ms += ms_between(t1, std::chrono::steady_clock::now());
         }
     }
 
@@ -451,16 +644,19 @@ public:
 
     std::string describe(int opt, long long n) const {
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        char buf[640];
+        char buf[1024];
         snprintf(buf, sizeof buf,
                  "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
-                 "\"band_width\": %d}",
+                 "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
+                 "\"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
-                 plan_.long_mode ? 1 : 0, band_width_);
+                 plan_.long_mode ? 1 : 0, band_width_, ragged_, ragged_stats_.launches,
+                 ragged_stats_.cells_padded > 0 ? ragged_stats_.cells_swept / ragged_stats_.cells_padded : 1.0,
+                 ragged_stats_.gather_ms, ragged_stats_.classify_ms, ragged_stats_.wait_ms, ragged_stats_.drain_ms);
         return buf;
     }
 
@@ -476,17 +672,17 @@ private:
         if (!gaps_ok) throw std::runtime_error("positive gap scores are not supported by the HIP kernels");
     }
 
-    LaunchPlan choose_plan(int force_g, int force_k) const {
+    LaunchPlan choose_plan(int R, int F, int force_g, int force_k) const {
         LaunchPlan best;
         double best_cost = 0;
         for (int i = 0; i < kNumGeometries; ++i) {
             const Geometry &g = kGeometries[i];
-            if (g.G * g.K < R_) continue;
+            if (g.G * g.K < R) continue;
             if (force_g && (g.G != force_g || (force_k && g.K != force_k))) continue;
             if (!force_g && force_k && g.K != force_k) continue;
             LaunchPlan p;
             p.geo = &g;
-            p.lds = g.lds(R_, F_);
+            p.lds = g.lds(R, F);
             p.pairs_per_wave = 2 * (kWave / g.G);
             // Block size: 4-wave blocks put one wave on each SIMD and measured fastest whenever two
             // of them fit a CU's 160 KiB of LDS; otherwise take the size that keeps most waves resident.
@@ -514,7 +710,7 @@ private:
             if (best_waves == 0) continue;
             // lane-steps per pair, weighted by instructions per step (per-row work + fixed part)
             const double per_step = g.K * (sc_.affine ? 11.0 : 7.0) + 14.0;
-            double cost = (double)(F_ + g.G - 1) * per_step * g.G / 2.0;
+            double cost = (double)(F + g.G - 1) * per_step * g.G / 2.0;
             if (best_waves < 8) cost *= 1.0 + 0.08 * (8 - best_waves);         // fewer than two waves per SIMD
             if (!best.geo || cost < best_cost) {
                 best = p;
@@ -523,8 +719,8 @@ private:
         }
         if (!best.geo || (getenv("VALIGN_HIP_FORCE_LONG") && !force_g)) {
             if (force_g || force_k)
-                throw std::runtime_error("the forced kernel geometry does not fit read_length=" + std::to_string(R_) +
-                                         ", ref_length=" + std::to_string(F_));
+                throw std::runtime_error("the forced kernel geometry does not fit read_length=" + std::to_string(R) +
+                                         ", ref_length=" + std::to_string(F));
             return long_plan();
         }
         return best;
@@ -592,7 +788,7 @@ private:
     }
 
     template <typename AlignmentT>
-    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) const {
+    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
         const size_t AL = (size_t)R_ + F_;
         auto work = [=](long long lo, long long hi) {
             for (long long i = lo; i < hi; ++i) {
@@ -607,21 +803,11 @@ private:
                 a.refEnd = idx[4 * i + 3];
             }
         };
-        if (threads <= 1 || cnt < 2048) {
-            work(0, cnt);
-            return;
-        }
-        std::vector<std::thread> pool;
-        const long long per = (cnt + threads - 1) / threads;
-        for (int t = 0; t < threads; ++t) {
-            const long long lo = t * per, hi = std::min(cnt, lo + per);
-            if (lo < hi) pool.emplace_back(work, lo, hi);
-        }
-        for (auto &th : pool) th.join();
+        for_ranges(threads, cnt, 2048, [&](int, long long lo, long long hi) { work(lo, hi); });
     }
 
     void release_staging() {
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < kSlots; ++s) {
             if (h_reads_[s]) (void)hipHostFree(h_reads_[s]);
             if (h_refs_[s]) (void)hipHostFree(h_refs_[s]);
             if (h_scores_[s]) (void)hipHostFree(h_scores_[s]);
@@ -639,7 +825,7 @@ private:
     void ensure_staging(long long pairs) {
         if (pairs <= staged_pairs_) return;
         release_staging();
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < kSlots; ++s) {
             hip_check(hipHostMalloc((void **)&h_reads_[s], std::max<size_t>((size_t)pairs * R_, 16), hipHostMallocDefault), "hipHostMalloc");
             hip_check(hipHostMalloc((void **)&h_refs_[s], std::max<size_t>((size_t)pairs * F_, 16), hipHostMallocDefault), "hipHostMalloc");
             hip_check(hipHostMalloc((void **)&h_scores_[s], sizeof(short) * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
@@ -650,8 +836,211 @@ private:
         staged_pairs_ = pairs;
     }
 
+    // ---- length-sorted batching (score_host, Smith-Waterman) ----
+
+    static double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    }
+
+    bool ragged_applies(int alg) const {
+        return ragged_ && alg == kAlgSW && !plan_.long_mode && !force_g_ && !force_k_ && score_width_ != 32 &&
+               R_ > 0 && F_ > 0 && int16_range_ok(alg);
+    }
+
+    // Share of the padded cells a length-sorted sweep would still visit, from 256 pairs spread over
+    // the call: sorting costs the host a pass over every tail, so it has to buy something.
+    double sampled_cell_fraction(const char *const *reads, const char *const *refs, long long n) const {
+        const long long samples = std::min<long long>(n, 256);
+        double swept = 0;
+        for (long long k = 0; k < samples; ++k) {
+            const long long i = k * n / samples;
+            const int r = read_caps_[read_class_[trimmed_length((const unsigned char *)reads[i], R_)]];
+            const int f = ref_caps_[ref_class_[trimmed_length((const unsigned char *)refs[i], F_)]];
+            swept += (double)r * f;
+        }
+        return swept / ((double)samples * R_ * F_);
+    }
+
+    // Read classes: the row capacities of the compiled geometries below read_length, then
+    // read_length itself.  Reference classes: multiples of 64 columns, then ref_length.
+    void build_length_classes() {
+        std::vector<int> caps;
+        for (int i = 0; i < kNumGeometries; ++i) {
+            const int rows = kGeometries[i].G * kGeometries[i].K;
+            if (rows < R_) caps.push_back(rows);
+        }
+        caps.push_back(R_);
+        std::sort(caps.begin(), caps.end());
+        caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
+        read_caps_ = caps;
+        ref_caps_.clear();
+        const int width = 64 * std::max(1, (F_ + 64 * kMaxScoreGroups - 1) / (64 * kMaxScoreGroups));
+        for (int c = width; c < F_; c += width) ref_caps_.push_back(c);
+        ref_caps_.push_back(F_);
+        read_class_.assign((size_t)R_ + 1, 0);
+        for (int len = 0, c = 0; len <= R_; ++len) {
+            while (read_caps_[c] < len) ++c;
+            read_class_[len] = (unsigned char)c;
+        }
+        ref_class_.assign((size_t)F_ + 1, 0);
+        for (int len = 0, c = 0; len <= F_; ++len) {
+            while (ref_caps_[c] < len) ++c;
+            ref_class_[len] = (unsigned short)c;
+        }
+        if (const char *m = getenv("VALIGN_HIP_RAGGED_MIN")) ragged_min_ = std::max(1, atoi(m));   // tuning switch
+    }
+
+    const LaunchPlan &class_plan(int R, int F) {
+        const std::pair<int, int> key(R, F);
+        auto it = class_plans_.find(key);
+        if (it == class_plans_.end()) it = class_plans_.emplace(key, choose_plan(R, F, 0, 0)).first;
+        return it->second;
+    }
+
+    static int trimmed_length(const unsigned char *s, int len) {
+        static const struct Table {
+            bool acgt[256] = {};
+            Table() { for (const char *p = "ACGTacgt"; *p; ++p) acgt[(unsigned char)*p] = true; }
+        } table;
+        while (len >= 8) {                      // NUL padding, eight bytes at a time
+            uint64_t tail;
+            memcpy(&tail, s + len - 8, 8);
+            if (tail != 0) break;
+            len -= 8;
+        }
+        while (len > 0 && !table.acgt[s[len - 1]]) --len;
+        return len;
+    }
+
+    // fn(part, lo, hi) over `threads` equal ranges of [0, cnt) on the persistent workers
+    template <typename Fn>
+    void for_ranges(int threads, long long cnt, long long serial_below, Fn fn) {
+        if (threads <= 1 || cnt < serial_below) {
+            fn(0, 0ll, cnt);
+            return;
+        }
+        if (!pool_ || pool_->workers() != threads - 1) pool_.reset(new WorkerPool(threads - 1));
+        const long long per = (cnt + threads - 1) / threads;
+        pool_->run(threads, [&](int t) {
+            const long long lo = t * per, hi = std::min(cnt, lo + per);
+            if (lo < hi) fn(t, lo, hi);
+        });
+    }
+
+    // Bin the chunk's pairs by trimmed length class, fold bins too small to be worth it into
+    // the next larger one, and copy every pair to its place in the pinned slot.  pos_[slot][i] is
+    // the position of pair i in the packed order.
+    std::vector<LengthGroup> gather_ragged(const char *const *reads, const char *const *refs, long long cnt, int slot,
+                                           int threads) {
+        const int NR = (int)read_caps_.size(), NF = (int)ref_caps_.size(), NG = NR * NF;
+        const int R = R_, F = F_;
+        if (threads > 1 && cnt < 4096) threads = 1;
+        std::vector<unsigned short> &bin = bin_[slot];
+        std::vector<int> &pos = pos_[slot];
+        bin.resize((size_t)cnt);
+        pos.resize((size_t)cnt);
+        std::vector<long long> counts((size_t)threads * NG, 0);
+        const unsigned char *rclass = read_class_.data();
+        const unsigned short *fclass = ref_class_.data();
+        const auto t_begin = std::chrono::steady_clock::now();
+        for_ranges(threads, cnt, 4096, [&, rclass, fclass](int t, long long lo, long long hi) {
+            long long *mine = counts.data() + (size_t)t * NG;
+            for (long long i = lo; i < hi; ++i) {
+                if (i + 8 < hi) {                 // the tails are one cache miss each: keep several in flight
+                    __builtin_prefetch(reads[i + 8] + (R > 8 ? R - 8 : 0));
+                    __builtin_prefetch(refs[i + 8] + (F > 8 ? F - 8 : 0));
+                }
+                const int rc = rclass[trimmed_length((const unsigned char *)reads[i], R)];
+                const int fc = fclass[trimmed_length((const unsigned char *)refs[i], F)];
+                bin[(size_t)i] = (unsigned short)(rc * NF + fc);
+                mine[rc * NF + fc] += 1;
+            }
+        });
+        ragged_stats_.classify_ms += ms_between(t_begin, std::chrono::steady_clock::now());
+        // fold: a read class with too few pairs for a launch of its own joins the next read class
+        // (bin by bin); inside a class, a reference bin smaller than a few blocks joins the next
+        // wider one.  Both dimensions only ever grow, so the padded sweep still covers the pair.
+        std::vector<long long> total((size_t)NG, 0);
+        for (int t = 0; t < threads; ++t)
+            for (int g = 0; g < NG; ++g) total[g] += counts[(size_t)t * NG + g];
+        std::vector<int> target((size_t)NG);
+        for (int g = 0; g < NG; ++g) target[g] = g;
+        const long long bin_min = std::min<long long>(ragged_min_, 256);
+        for (int rc = 0; rc < NR; ++rc) {
+            long long in_class = 0;
+            for (int fc = 0; fc < NF; ++fc) in_class += total[rc * NF + fc];
+            if (in_class == 0) continue;
+            if (in_class < ragged_min_ && rc < NR - 1) {
+                for (int fc = 0; fc < NF; ++fc) {
+                    const int g = rc * NF + fc;
+                    total[g + NF] += total[g];
+                    total[g] = 0;
+                    target[g] = g + NF;
+                }
+                continue;
+            }
+            for (int fc = 0; fc < NF - 1; ++fc) {
+                const int g = rc * NF + fc;
+                if (total[g] == 0 || total[g] >= bin_min) continue;
+                total[g + 1] += total[g];
+                total[g] = 0;
+                target[g] = g + 1;
+            }
+        }
+        for (int g = NG - 1; g >= 0; --g) target[g] = target[target[g]];      // targets only point forward
+        std::vector<LengthGroup> groups;
+        std::vector<int> group_of((size_t)NG, -1);
+        long long pair_ofs = 0;
+        size_t read_ofs = 0, ref_ofs = 0;
+        for (int g = 0; g < NG; ++g) {
+            if (total[g] == 0) continue;
+            LengthGroup lg;
+            lg.R = read_caps_[g / NF];
+            lg.F = ref_caps_[g % NF];
+            lg.pairs = total[g];
+            lg.pair_ofs = pair_ofs;
+            lg.read_ofs = read_ofs;
+            lg.ref_ofs = ref_ofs;
+            pair_ofs += lg.pairs;
+            read_ofs += (size_t)lg.pairs * lg.R;
+            ref_ofs += (size_t)lg.pairs * lg.F;
+            group_of[g] = (int)groups.size();
+            groups.push_back(lg);
+        }
+        // first packed position of every (thread, group)
+        const int NL = (int)groups.size();
+        std::vector<long long> start((size_t)threads * NL, 0);
+        {
+            std::vector<long long> run((size_t)NL, 0);
+            for (int t = 0; t < threads; ++t) {
+                for (int l = 0; l < NL; ++l) start[(size_t)t * NL + l] = run[l];
+                for (int g = 0; g < NG; ++g)
+                    if (counts[(size_t)t * NG + g]) run[group_of[target[g]]] += counts[(size_t)t * NG + g];
+            }
+        }
+        uint8_t *dst_reads = h_reads_[slot], *dst_refs = h_refs_[slot];
+        const LengthGroup *gl = groups.data();
+        for_ranges(threads, cnt, 4096, [&, gl, dst_reads, dst_refs](int t, long long lo, long long hi) {
+            long long *next = start.data() + (size_t)t * NL;
+            for (long long i = lo; i < hi; ++i) {
+                if (i + 4 < hi) {
+                    __builtin_prefetch(reads[i + 4]);
+                    __builtin_prefetch(refs[i + 4]);
+                    __builtin_prefetch(refs[i + 4] + 64);
+                }
+                const int l = group_of[target[bin[(size_t)i]]];
+                const LengthGroup &g = gl[l];
+                const long long k = next[l]++;
+                pos[(size_t)i] = (int)(g.pair_ofs + k);
+                memcpy(dst_reads + g.read_ofs + (size_t)k * g.R, reads[i], (size_t)g.R);
+                memcpy(dst_refs + g.ref_ofs + (size_t)k * g.F, refs[i], (size_t)g.F);
+            }
+        });
+        return groups;
+    }
+
     void gather(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads,
-                uint8_t *dst_refs, int threads) const {
+                uint8_t *dst_refs, int threads) {
         const int R = R_, F = F_;
         auto work = [=](long long lo, long long hi) {
             for (long long i = lo; i < hi; ++i) {
@@ -659,17 +1048,7 @@ private:
                 memcpy(dst_refs + (size_t)i * F, refs[i], (size_t)F);
             }
         };
-        if (threads <= 1 || cnt < 4096) {
-            work(0, cnt);
-            return;
-        }
-        std::vector<std::thread> pool;
-        const long long per = (cnt + threads - 1) / threads;
-        for (int t = 0; t < threads; ++t) {
-            const long long lo = t * per, hi = std::min(cnt, lo + per);
-            if (lo < hi) pool.emplace_back(work, lo, hi);
-        }
-        for (auto &th : pool) th.join();
+        for_ranges(threads, cnt, 4096, [&](int, long long lo, long long hi) { work(lo, hi); });
     }
 
     int device_, R_, F_;
@@ -677,17 +1056,28 @@ private:
     bool sse_policy_ = false;
     int band_width_ = 0;
     int score_width_ = 0;
+    int ragged_ = 1, force_g_ = 0, force_k_ = 0;
+    long long ragged_min_ = 2048;                             // pairs a length bin needs for its own launch
+    std::vector<int> read_caps_, ref_caps_;
+    std::vector<unsigned char> read_class_;
+    std::vector<unsigned short> ref_class_;
+    std::map<std::pair<int, int>, LaunchPlan> class_plans_;
+    std::vector<unsigned short> bin_[kSlots];
+    std::vector<int> pos_[kSlots];
+    std::unique_ptr<WorkerPool> pool_;
+    bool slot_ragged_[kSlots] = {};
+    RaggedStats ragged_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     std::string arch_;
     LaunchPlan plan_;
-    hipStream_t streams_[2] = {nullptr, nullptr};
-    hipEvent_t slot_done_[2] = {nullptr, nullptr};
-    long long slot_begin_[2] = {0, 0}, slot_pending_[2] = {0, 0};
+    hipStream_t streams_[kSlots] = {};
+    hipEvent_t slot_done_[kSlots] = {};
+    long long slot_begin_[kSlots] = {}, slot_pending_[kSlots] = {};
     long long staged_pairs_ = 0;
-    uint8_t *h_reads_[2] = {nullptr, nullptr}, *h_refs_[2] = {nullptr, nullptr};
-    short *h_scores_[2] = {nullptr, nullptr};
-    uint8_t *d_reads_[2] = {nullptr, nullptr}, *d_refs_[2] = {nullptr, nullptr};
-    int16_t *d_scores_[2] = {nullptr, nullptr};
+    uint8_t *h_reads_[kSlots] = {}, *h_refs_[kSlots] = {};
+    short *h_scores_[kSlots] = {};
+    uint8_t *d_reads_[kSlots] = {}, *d_refs_[kSlots] = {};
+    int16_t *d_scores_[kSlots] = {};
     // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
     unsigned *d_brow_ = nullptr;       // long-read path: strip boundary rows
     size_t brow_bytes_ = 0;

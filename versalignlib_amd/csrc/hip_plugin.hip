@@ -69,6 +69,7 @@ public:
             engine_->set_traceback_policy(opt_param("traceback_policy", 0));
             engine_->set_band_width(opt_param("band_width", 0));
             engine_->set_score_width(opt_param("score_width", 0));
+            engine_->set_ragged_batching(opt_param("ragged_batching", 1));
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
@@ -200,6 +201,14 @@ VALIGN_EXPORT int valign_hip_set_score_width(valign_hip_engine *e, int bits) {
         return 1;
     }
     return flat_guard([&] { e->impl->set_score_width(bits); });
+}
+
+VALIGN_EXPORT int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_ragged_batching(mode); });
 }
 
 VALIGN_EXPORT int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy) {

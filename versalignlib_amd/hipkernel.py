@@ -62,6 +62,7 @@ def lib():
         L.valign_hip_set_traceback_policy.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_band_width.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_score_width.argtypes = [vp, ctypes.c_int]
+        L.valign_hip_set_ragged_batching.argtypes = [vp, ctypes.c_int]
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
         L.valign_hip_align_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp, vp]
         L.valign_hip_score_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int]
@@ -75,7 +76,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_set_traceback_policy", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -107,6 +108,12 @@ class Engine:
     def set_score_width(self, bits):
         """0 auto (int16, int32 where needed), 16, or 32."""
         if lib().valign_hip_set_score_width(self._h, int(bits)) != 0:
+            raise HipKernelError(_err())
+
+    def set_ragged_batching(self, mode):
+        """Length-sorted Smith-Waterman score batches on the host-pointer path: 0 never, 1 when the
+        call is ragged enough (default), 2 always."""
+        if lib().valign_hip_set_ragged_batching(self._h, int(mode)) != 0:
             raise HipKernelError(_err())
 
     def set_band_width(self, diagonals):
@@ -150,8 +157,25 @@ class Engine:
             raise HipKernelError(_err())
         return rows, idx
 
+    def score_host(self, opt, reads, refs, threads=1):
+        """Host-pointer path of score_alignments without the plugin object: reads/refs are C-contiguous
+        numpy uint8 arrays [n, R] / [n, F]; the library gets one pointer per sequence."""
+        import numpy as np
+        n = reads.shape[0]
+        assert reads.dtype == np.uint8 and refs.dtype == np.uint8
+        assert reads.flags.c_contiguous and refs.flags.c_contiguous
+        assert tuple(reads.shape) == (n, self.read_length) and tuple(refs.shape) == (n, self.ref_length)
+        rp = (reads.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.read_length)).astype(np.uint64)
+        fp = (refs.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.ref_length)).astype(np.uint64)
+        scores = np.zeros(n, dtype=np.int16)
+        rc = lib().valign_hip_score_host(self._h, int(opt), n, rp.ctypes.data, fp.ctypes.data,
+                                         scores.ctypes.data, int(threads))
+        if rc != 0:
+            raise HipKernelError(_err())
+        return scores
+
     def describe(self, opt=0, n=0):
-        buf = ctypes.create_string_buffer(1024)
+        buf = ctypes.create_string_buffer(2048)
         lib().valign_hip_describe(self._h, int(opt), int(n), buf, len(buf))
         return json.loads(buf.value.decode())
 

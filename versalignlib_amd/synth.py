@@ -106,6 +106,26 @@ def make_pairs(n, R, F, seed=1, sub_rate=0.15, indel_rate=0.0, n_run_frac=0.01,
     return np.ascontiguousarray(reads), np.ascontiguousarray(refs)
 
 
+def make_ragged_pairs(n, R, F, seed=1, min_read_frac=0.1, min_ref_frac=0.1, trailing_n_frac=0.05, **kw):
+    """make_pairs, then every read and ref keeps a uniformly drawn prefix and the rest becomes the
+    NUL padding the reference host's pad() appends (src/util/versalignUtil.cpp:17-33): what a FASTA
+    of mixed lengths looks like at the plugin boundary.  trailing_n_frac of the pairs end in a short
+    run of 'N' before the padding."""
+    reads, refs = make_pairs(n, R, F, seed=seed, **kw)
+    if n == 0:
+        return reads, refs
+    u = _uniform(seed, 20, (n, 3))
+    keep_r = np.minimum(R, (R * (min_read_frac + (1 - min_read_frac) * u[:, 0])).astype(np.int64) + 1)
+    keep_f = np.minimum(F, (F * (min_ref_frac + (1 - min_ref_frac) * u[:, 1])).astype(np.int64) + 1)
+    reads[np.arange(R)[None, :] >= keep_r[:, None]] = 0
+    refs[np.arange(F)[None, :] >= keep_f[:, None]] = 0
+    tail = u[:, 2] < trailing_n_frac
+    for i in np.nonzero(tail)[0]:
+        reads[i, max(0, keep_r[i] - 3):keep_r[i]] = ord("N")
+        refs[i, max(0, keep_f[i] - 2):keep_f[i]] = ord("n")
+    return np.ascontiguousarray(reads), np.ascontiguousarray(refs)
+
+
 def cells(n, R, F):
     """DP cell updates of a batch: every pair costs exactly R*F (padding is computed)."""
     return int(n) * int(R) * int(F)
