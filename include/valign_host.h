@@ -18,6 +18,7 @@
  *   vh_close ................. clear_kernel            (src/impl/main.cpp:217-225)
  *   vh_pad ................... pad()                   (src/util/versalignUtil.cpp:17-33)
  *   vh_parse_fasta ........... FastaProvider           (src/util/versalignUtil.h:52-92)
+ *   vh_cigar ................. (none; the rows main.cpp:147-189 prints, run-length encoded)
  *
  * All functions return 0 on success and a negative value on failure unless stated
  * otherwise; vh_last_error() gives the message of the most recent failure on the
@@ -101,6 +102,17 @@ int vh_parse_fasta(const char *path, char **blob, int *count);
 /* Right-pad `count` NUL-terminated strings (laid end to end in blob) with `fill` to
  * the longest length; writes count * (*length) bytes into a malloc'ed *out.         */
 int vh_pad(const char *blob, int count, char fill, uint8_t **out, int *length);
+
+/* CIGAR of one alignment as compute_alignments returns it (two gapped rows of read_length +
+ * ref_length bytes, Alignment::readStart .. readEnd-1 are the used columns, the last one the NUL
+ * the kernels write): a column with a base in both rows is M (extended != 0: '=' where the two
+ * bytes are equal ignoring case, else 'X'), a '-' in the ref row is I (base only in the read), a '-'
+ * in the read row is D.  The reference has no CIGAR writer -- its host prints the two rows
+ * (src/impl/main.cpp:147-189); this is the same information run-length encoded.  Writes a
+ * NUL-terminated string into buf; returns its length, or -1 when cap is too small / bad input.
+ * An empty alignment gives "".                                                                   */
+int vh_cigar(const uint8_t *read_row, const uint8_t *ref_row, int start, int end, int extended,
+             char *buf, int cap);
 
 void vh_free(void *ptr);
 

@@ -72,8 +72,13 @@ def test_cli_with_reference_default_kernel(tmp_path):
     if not default:
         pytest.skip("oracle/_ref not built")
     reads, refs = _batch(tmp_path)
-    out, stdout = _run_cli(default, tmp_path)
+    out, stdout = _run_cli(default, tmp_path, extra=("--cigar",))
     _check_outputs(out, reads, refs, full_scores=False)
+    for opt, tag in ((0, "smith_waterman"), (1, "needleman_wunsch")):      # --cigar: one more file per mode
+        rows, idx = cpu_ref.align(opt, reads, refs)
+        lines = (out / ("cigars_%s.txt" % tag)).read_text().splitlines()
+        assert [ln.split("\t")[1] if "\t" in ln else "" for ln in lines] == \
+            [c for c in host.cigars(rows, idx, extended=True)]
     table = stdout.splitlines()
     assert table[0] == "Threads\t1\t2" and table[1].startswith(default) and len(table[1].split("\t")) == 3
 

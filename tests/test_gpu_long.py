@@ -128,3 +128,17 @@ def test_largest_shape_the_abi_allows():
     assert np.array_equal(got, cpu_ref.score(0, reads, refs, threads=8, wide=True))
     with pytest.raises(host.PluginError, match="16-bit coordinates"):
         host.Plugin(build.HIP_PLUGIN, R + 1, F)
+
+
+def test_long_path_over_many_staging_chunks(forced_long, monkeypatch):
+    """Host-pointer calls cycle through the pinned slots; strip kernels share one boundary-row scratch,
+    so their chunks must run back to back on one stream -- eight chunks against the oracle."""
+    monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(256 << 10))       # 1024-pair chunks
+    R, F, blk = 330, 420, 2048
+    r0, f0 = synth.make_pairs(blk, R, F, seed=31, indel_rate=0.01, n_run_frac=0.02, short_frac=0.05)
+    reads, refs = np.tile(r0, (4, 1)), np.tile(f0, (4, 1))
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as hip:
+        for opt in (0, 1):
+            exp = cpu_ref.score(opt, r0, f0, threads=8)
+            got = hip.score_alignments(opt, reads, refs)
+            assert np.array_equal(got, np.tile(exp, 4)), opt

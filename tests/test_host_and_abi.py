@@ -112,3 +112,24 @@ def test_constructor_refuses_what_the_kernels_cannot_compute():
         host.Plugin(build.HIP_PLUGIN, 20000, 20000)
     with pytest.raises(host.PluginError, match="outside int16"):
         host.Plugin(build.HIP_PLUGIN, 10, 10, score_match=70000)
+
+
+def test_cigar_of_known_answer_alignments():
+    """CIGARs of the Appendix-C known answers (oracle alignments; SURVEY Appendix C #5: the NW
+    alignment ACGTTTGACC / ACG--TGACC has two read bases without a partner)."""
+    from oracle import cpu_ref
+    reads = host.pad([b"ACGTTTGACC", b"GATTACA", b"AAAA"])
+    refs = host.pad([b"ACGTGACC", b"GCATGCT", b"CCCCCCCC"])
+    rows, idx = cpu_ref.align(host.NW, reads, refs)
+    assert host.cigars(rows, idx) == ["3M2I5M", "7M", "4M"]
+    assert host.cigars(rows, idx, extended=True) == ["3=2I5=", "1=2X1=1X1=1X", "4X"]
+    rows, idx = cpu_ref.align(host.SW, reads, refs)
+    assert host.cigars(rows, idx) == ["5M", "2M", ""]            # KAT 4: empty local alignment
+    # a deletion from the read's point of view
+    rows, idx = cpu_ref.align(host.NW, host.pad([b"ACGTGACC"]), host.pad([b"ACGTTTGACC"]))
+    assert "D" in host.cigars(rows, idx)[0]
+    with pytest.raises(host.PluginError):
+        buf = ctypes.create_string_buffer(2)
+        r = np.ascontiguousarray(rows[0])
+        if host.lib().vh_cigar(r.ctypes.data, r.ctypes.data + r.shape[1], int(idx[0, 0]), int(idx[0, 1]), 0, buf, 2) < 0:
+            raise host.PluginError("too small")

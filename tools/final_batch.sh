@@ -22,5 +22,13 @@ python tools/align_bench.py --iters 3 > $OUT/align_$TAG.log 2>&1 || exit 1
 { python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 ;
   python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 --affine 1 ; } > $OUT/geom_$TAG.log 2>&1 || exit 1
 echo "sweeps done"
-python tools/abi_bench.py --pairs 1048576 --align-pairs 262144 --threads 32 > $OUT/abi_$TAG.log 2>&1 || exit 1
+python tools/abi_bench.py --pairs 1048576 --align-pairs 262144 --threads 16 > $OUT/abi_$TAG.log 2>&1 || exit 1
 echo "abi done"
+# host-pointer path: phases, mixed-length batches, small-call latency, raw PCIe and gather rates
+{ echo "# tools/host_path_profile.py --threads 8,16"; python tools/host_path_profile.py --threads 8,16;
+  echo "# tools/abi_bench.py --pairs 1048576 --threads 16 --ragged"; python tools/abi_bench.py --pairs 1048576 --threads 16 --ragged;
+  echo "# tools/latency_bench.py"; python tools/latency_bench.py;
+  echo "# tools/microbench/pcie_rate.py"; python tools/microbench/pcie_rate.py;
+  echo "# tools/microbench/gather_rate.hip"; hipcc -O2 --offload-arch=gfx950 -o /tmp/gather_rate tools/microbench/gather_rate.hip -lpthread && /tmp/gather_rate;
+  echo "# nproc / cpu.max"; nproc; cat /sys/fs/cgroup/cpu.max; } 2>&1 | grep -v amdgpu.ids > $OUT/host_path_$TAG.log || exit 1
+echo "host path done"

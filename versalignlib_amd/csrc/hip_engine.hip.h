@@ -422,7 +422,7 @@ public:
         if (alg > 1 || n <= 0) return;
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const size_t per_pair = (size_t)R_ + F_;
-        long long chunk = per_pair ? (long long)((48u << 20) / per_pair) : n;
+        long long chunk = per_pair ? (long long)(score_chunk_bytes_ / per_pair) : n;
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
         ensure_staging(chunk);
@@ -888,6 +888,7 @@ private:
             ref_class_[len] = (unsigned short)c;
         }
         if (const char *m = getenv("VALIGN_HIP_RAGGED_MIN")) ragged_min_ = std::max(1, atoi(m));   // tuning switch
+        if (const char *m = getenv("VALIGN_HIP_CHUNK_BYTES")) score_chunk_bytes_ = (size_t)std::max(4096ll, atoll(m));
     }
 
     const LaunchPlan &class_plan(int R, int F) {
@@ -1057,6 +1058,7 @@ private:
     int band_width_ = 0;
     int score_width_ = 0;
     int ragged_ = 1, force_g_ = 0, force_k_ = 0;
+    size_t score_chunk_bytes_ = 48u << 20;                   // staging chunk of score_host (VALIGN_HIP_CHUNK_BYTES)
     long long ragged_min_ = 2048;                             // pairs a length bin needs for its own launch
     std::vector<int> read_caps_, ref_caps_;
     std::vector<unsigned char> read_class_;

@@ -9,11 +9,13 @@
 //
 //   valign-bench --kernel <plugin.so> --reads reads.fa --refs refs.fa [--out-dir DIR]
 //                [--threads 10] [--ladder 1,2,4,8] [--loops 100] [--time score|align|none]
-//                [--param key=value ...]
+//                [--param key=value ...] [--cigar]
 //
 // Output files (same names and line formats as the reference):
 //   scores_smith_waterman.txt / scores_needleman_wunsch.txt ....... "<read>\t<score>"
 //   alignments_smith_waterman.txt / alignments_needleman_wunsch.txt  "<read row>\n<ref row>\n\n"
+// With --cigar also cigars_smith_waterman.txt / cigars_needleman_wunsch.txt: "<read>\t<CIGAR>" (=/X/I/D;
+// not a reference format -- the reference only prints the gapped rows).
 // Timing table on stdout: "Threads\t<t1>\t<t2>...\n<kernel>\t<us per call>..." (main.cpp:197-212,292).
 #include "valign_host.h"
 
@@ -30,6 +32,7 @@ namespace {
 struct Options {
     std::string kernel, reads, refs, out_dir = ".", time_mode = "align";
     int threads = 10, loops = 100;
+    bool cigar = false;
     std::vector<int> ladder = {1, 2, 4, 8, 16, 32, 64};
     std::vector<std::pair<std::string, int>> params;
 };
@@ -54,6 +57,7 @@ Options parse(int argc, char **argv) {
         else if (a == "--threads") o.threads = atoi(next().c_str());
         else if (a == "--loops") o.loops = atoi(next().c_str());
         else if (a == "--time") o.time_mode = next();
+        else if (a == "--cigar") o.cigar = true;
         else if (a == "--ladder") {
             o.ladder.clear();
             std::string v = next();
@@ -112,7 +116,8 @@ std::string c_text(const uint8_t *s, int max_len) {
     return std::string((const char *)s, (size_t)n);
 }
 
-void run_mode(vh_plugin *p, int opt, const char *tag, const Batch &reads, const Batch &refs, const std::string &dir) {
+void run_mode(vh_plugin *p, int opt, const char *tag, const Batch &reads, const Batch &refs, const std::string &dir,
+              bool cigar) {
     const int n = reads.count, AL = reads.length + refs.length;
     std::vector<int16_t> scores((size_t)n, 0);
     if (vh_score(p, opt, n, reads.data, refs.data, scores.data()) != 0) die(vh_last_error());
@@ -132,6 +137,16 @@ void run_mode(vh_plugin *p, int opt, const char *tag, const Batch &reads, const 
         fprintf(f, "%s\n%s\n\n", c_text(rr + rs, AL - rs).c_str(), c_text(fr + fs, AL - fs).c_str());
     }
     fclose(f);
+    if (!cigar) return;
+    f = fopen((dir + "/cigars_" + tag + ".txt").c_str(), "w");
+    if (!f) die("cannot write into " + dir);
+    std::vector<char> text((size_t)4 * AL + 16);
+    for (int i = 0; i < n; ++i) {
+        const uint8_t *rr = rows.data() + (size_t)i * 2 * AL;
+        if (vh_cigar(rr, rr + AL, idx[4 * i], idx[4 * i + 1], 1, text.data(), (int)text.size()) < 0) die(vh_last_error());
+        fprintf(f, "%s\t%s\n", c_text(reads.data + (size_t)i * reads.length, reads.length).c_str(), text.data());
+    }
+    fclose(f);
 }
 
 }  // namespace
@@ -144,10 +159,10 @@ int main(int argc, char **argv) {
         return -1;
     }
     vh_plugin *p = spawn(o, reads.length, refs.length, o.threads);
-    run_mode(p, 0, "smith_waterman", reads, refs, o.out_dir);
+    run_mode(p, 0, "smith_waterman", reads, refs, o.out_dir, o.cigar);
     vh_close(p);
     p = spawn(o, reads.length, refs.length, o.threads);     // the reference respawns per mode
-    run_mode(p, 1, "needleman_wunsch", reads, refs, o.out_dir);
+    run_mode(p, 1, "needleman_wunsch", reads, refs, o.out_dir, o.cigar);
     vh_close(p);
 
     if (o.time_mode != "none") {

@@ -362,6 +362,47 @@ int vh_pad(const char *blob, int count, char fill, uint8_t **out, int *length) {
     return 0;
 }
 
+int vh_cigar(const uint8_t *read_row, const uint8_t *ref_row, int start, int end, int extended, char *buf,
+             int cap) {
+    if (!read_row || !ref_row || !buf || cap <= 0 || start < 0 || end < start) {
+        fail("bad argument");
+        return -1;
+    }
+    int len = 0, run = 0;
+    char op = 0;
+    auto flush = [&]() -> bool {
+        if (run == 0) return true;
+        char tmp[16];
+        const int w = snprintf(tmp, sizeof tmp, "%d%c", run, op);
+        if (len + w >= cap) return false;
+        memcpy(buf + len, tmp, (size_t)w);
+        len += w;
+        run = 0;
+        return true;
+    };
+    for (int c = start; c < end; ++c) {
+        const uint8_t a = read_row[c], b = ref_row[c];
+        if (a == 0 && b == 0) break;                      // the terminating NUL column
+        char now;
+        if (a == '-' && b != '-') now = 'D';
+        else if (b == '-' && a != '-') now = 'I';
+        else if (!extended) now = 'M';
+        else now = ((a | 0x20) == (b | 0x20)) ? '=' : 'X';
+        if (now != op && !flush()) {
+            fail("CIGAR buffer too small");
+            return -1;
+        }
+        op = now;
+        ++run;
+    }
+    if (!flush()) {
+        fail("CIGAR buffer too small");
+        return -1;
+    }
+    buf[len] = 0;
+    return len;
+}
+
 void vh_free(void *ptr) { free(ptr); }
 
 }  // extern "C"

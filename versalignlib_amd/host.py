@@ -51,6 +51,8 @@ def lib():
                                      ctypes.POINTER(ctypes.c_int)]
         L.vh_pad.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char,
                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+        L.vh_cigar.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_char_p, ctypes.c_int]
         L.vh_free.restype = None
         L.vh_free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -191,6 +193,23 @@ def parse_fasta(path):
         out.append(s)
         off += len(s) + 1
     lib().vh_free(blob)
+    return out
+
+
+def cigars(rows, idx, extended=False):
+    """CIGAR strings of compute_alignments' output (rows uint8 [n, 2, R+F], idx int16 [n, 4]):
+    M (or =/X), I = base only in the read, D = base only in the reference."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, AL = rows.shape[0], rows.shape[2]
+    buf = ctypes.create_string_buffer(4 * AL + 16)
+    out = []
+    for i in range(n):
+        base = rows.ctypes.data + i * 2 * AL
+        got = lib().vh_cigar(base, base + AL, int(idx[i, 0]), int(idx[i, 1]), 1 if extended else 0,
+                             buf, len(buf))
+        if got < 0:
+            raise PluginError(_err())
+        out.append(buf.value.decode())
     return out
 
 
