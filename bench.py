@@ -56,6 +56,26 @@ def measured_traffic(kernel_key, pairs):
         return None
 
 
+def measured_valu_issue(kernel_key, pairs):
+    """The resource that does bind this kernel: share of all SIMD cycles spent issuing VALU
+    instructions, from the same committed PMC passes.  Packed-int16 ops issue one wave64
+    instruction per 4 cycles per SIMD (profiles/r01_valu_rate_microbench.txt); 256 CUs x 4 SIMDs;
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    try:
+        with open(PMC_PROFILE) as f:
+            prof = json.load(f)
+        k = prof["kernels"][kernel_key]
+        if int(prof["pairs"]) != int(pairs):
+            return None
+        issue = float(k["SQ_INSTS_VALU"]) * 4.0 / 1024.0
+        cycles = float(k["GRBM_GUI_ACTIVE"]) / 8.0
+        return {"bound": "valu-issue", "wave_instructions": float(k["SQ_INSTS_VALU"]),
+                "issue_cycles_per_simd": round(issue), "kernel_cycles": round(cycles),
+                "frac": round(issue / cycles, 4), "source": "profiles/r01_pmc_final.json"}
+    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
+        return None
+
+
 def synth_on_device(n, device, seed):
     """SURVEY.md 8(d) batch, generated on the GPU: uniform ACGT refs; reads = ref window
     with 15% substitutions; 1% of pairs carry an N run, 1% are short and NUL padded."""
@@ -227,7 +247,8 @@ def main():
                          "kernel": "score_kernel<%d,%d,SW,affine>" % (d["group_lanes"], d["rows_per_lane"]),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
                          "kernel_gcups": round(n * R * F / (k_ms * 1e-3) / 1e9, 1),
-                         "note": "integer VALU bound: %.4f B/cell algorithmic, HBM is idle by design" % ((R + F + 2) / (R * F))},
+                         "note": "integer VALU bound: %.4f B/cell algorithmic, HBM is idle by design" % ((R + F + 2) / (R * F)),
+                         "valu": measured_valu_issue("score_kernel<%d, %d, 0, 3>" % (d["group_lanes"], d["rows_per_lane"]), n)},
         }
         lin_ms = kernel_launch_ms(eng_lin, 0, reads, refs, local, 5)
         line["linear_gap"] = {"kernel_ms": round(lin_ms, 4), "kernel_gcups": round(n * R * F / (lin_ms * 1e-3) / 1e9, 1),

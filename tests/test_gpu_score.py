@@ -154,6 +154,27 @@ def test_symmetric_and_asymmetric_affine_kernels(aff):
             assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])
 
 
+@pytest.mark.parametrize("match,cells", [(13, "f16"), (14, "int16")])
+def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
+    """Symmetric affine Smith-Waterman runs on packed half floats while every value stays an integer of
+    magnitude <= 2048 (150 x 13 = 1950), on int16 beyond (150 x 14 = 2100).  Perfect matches drive the
+    scores to the top of the range; both must equal the oracle."""
+    R, F, n = 150, 500, 600
+    reads, refs = synth.make_pairs(n, R, F, seed=81, sub_rate=0.0, n_run_frac=0.0, short_frac=0.0)
+    noisy, _ = synth.make_pairs(n, R, F, seed=81, sub_rate=0.1, n_run_frac=0.0, short_frac=0.0)
+    reads[n // 2:] = noisy[n // 2:]
+    aff = dict(open_read=-20, ext_read=-3, open_ref=-20, ext_ref=-3)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(match, -11, -20, -20, **aff))
+    assert eng.describe(host.SW)["score_cells"] == cells
+    assert eng.describe(host.NW)["score_cells"] == "int16"
+    import torch
+    got = eng.score_device(host.SW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+    exp = cpu_ref.score(host.SW, reads, refs, cpu_ref.Scoring.make(match, -11, -20, -20, **aff), threads=8, affine=True)
+    assert exp.max() == 150 * match
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:8]
+    eng.close()
+
+
 def test_int16_range_is_checked_per_call():
     """A shape whose cells could leave int16 never wraps silently (as the reference would): scores
     move to int32 cells, alignments (int16 only) are refused loudly."""

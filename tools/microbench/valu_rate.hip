@@ -7,6 +7,7 @@
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define ITER 4096
 #define UNROLL 16
@@ -30,7 +31,21 @@ __global__ void __launch_bounds__(512) rate(unsigned *out, unsigned seed, long l
             if (OP == 4) r[i] = r[i] + g;                                                         // v_add_u32
             if (OP == 5) r[i] = (unsigned)max((int)r[i], (int)g);                                 // v_max_i32
             if (OP == 6) a = __builtin_elementwise_add_sat(a, b);                                 // v_pk_add_i16 clamp
-            if (OP != 3 && OP != 4 && OP != 5) r[i] = __builtin_bit_cast(unsigned, a);
+            if (OP == 7) {                                                                          // v_pk_add_f16
+                f16x2 x = __builtin_bit_cast(f16x2, r[i]) + __builtin_bit_cast(f16x2, g);
+                r[i] = __builtin_bit_cast(unsigned, x);
+            }
+            if (OP == 8) {                                                                          // v_pk_maximum3_f16
+                f16x2 x = __builtin_elementwise_maximum(
+                    __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, r[i]), __builtin_bit_cast(f16x2, g)),
+                    __builtin_bit_cast(f16x2, r[(i + 1) % UNROLL]));
+                r[i] = __builtin_bit_cast(unsigned, x);
+            }
+            if (OP == 9) {                                                                          // 2-operand maximum
+                f16x2 x = __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, r[i]), __builtin_bit_cast(f16x2, g));
+                r[i] = __builtin_bit_cast(unsigned, x);
+            }
+            if (OP != 3 && OP != 4 && OP != 5 && OP < 7) r[i] = __builtin_bit_cast(unsigned, a);
             asm volatile("" : "+v"(r[i]));
         }
     }
@@ -87,5 +102,8 @@ int main() {
     run<3>("v_perm_b32 + v_xor");
     run<4>("v_add_u32");
     run<5>("v_max_i32");
+    run<7>("v_pk_add_f16");
+    run<8>("v_pk_maximum3_f16");
+    run<9>("f16x2 maximum(a, b)");
     return 0;
 }

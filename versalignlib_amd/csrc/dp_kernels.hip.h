@@ -44,6 +44,7 @@
 namespace valign {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
@@ -382,6 +383,12 @@ constexpr int kGapLinear = 0;
 constexpr int kGapSym = 1;
 constexpr int kGapAffine = 2;
 constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_read == ext_ref
+// The same recurrence as kGapAffineSym for Smith-Waterman on packed half floats: every value is an
+// integer of magnitude <= 2048, which fp16 represents exactly, and gfx950's v_pk_maximum3_f16
+// takes three operands -- h = max3(diag + S, E, F), E = max3(E - ext, H - open, 0) (which floors the
+// whole cell at zero) and the maximum tracking two rows at a time: 8.5 instead of 10 packed
+// instructions per register.  The engine picks it when shape x scoring stays inside +-2048.
+constexpr int kGapAffineSymF16 = 4;
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
 
@@ -389,7 +396,9 @@ template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
     using geo = Geo<G, K>;
-    constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym;
+    constexpr bool F16 = GAPS == kGapAffineSymF16;
+    static_assert(!F16 || ALG == kAlgSW, "the half-float recurrence is Smith-Waterman only");
+    constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym || F16;
     constexpr bool SYM = GAPS == kGapSym;
     constexpr bool AFFSYM = GAPS == kGapAffineSym;
     const int lane = threadIdx.x & (kWave - 1);
@@ -414,8 +423,11 @@ score_kernel(const ScoreArgs args) {
     }
 
     WaveTables w;
+    // the query profile holds the substitution scores in the cell format of the recurrence
+    const short s_match = F16 ? __builtin_bit_cast(short, (_Float16)(int)args.match) : args.match;
+    const short s_mismatch = F16 ? __builtin_bit_cast(short, (_Float16)(int)args.mismatch) : args.mismatch;
     if (!wave_setup<G, K, false>(reads, refs, n_pairs, args.R, F_batch, args.prof_area, args.refc_stride,
-                                 args.wave_lds, args.match, args.mismatch, w, false, block))
+                                 args.wave_lds, s_match, s_mismatch, w, false, block))
         return;
     const long long pair0 = w.pair0;
     // Smith-Waterman: columns after the last ACGT base of every reference in the wave (the NUL
@@ -439,6 +451,9 @@ score_kernel(const ScoreArgs args) {
         o_ref = pk(args.open_ref);    e_ref = pk(args.ext_ref);
     }
     const s16x2 border_f = pk(ALG == kAlgNW ? kNegInf : (short)0);
+    // half-float recurrence: signed addends (open, extend <= 0)
+    const _Float16 open_h = (_Float16)(int)args.open_ref, ext_h = (_Float16)(int)args.ext_ref;
+    const f16x2 o_half = f16x2{open_h, open_h}, e_half = f16x2{ext_h, ext_h}, zero_half = f16x2{(_Float16)0, (_Float16)0};
 
     // Hl: H of the previous column; El: E of the previous column; HOl (symmetric affine only):
     // H - open of the previous column, which feeds E of this column (and, within a column, F of
@@ -503,7 +518,42 @@ score_kernel(const ScoreArgs args) {
                 const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
                 fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             }
-            if (SYM) {
+            if (F16) {
+                // Registers hold two half floats (bit patterns in the s16x2 containers).  pass1(q) -- diag + S
+                // and E of row q, which only need the previous column -- is written between the links of the
+                // dependent chain down the column (F, H, H - open), one row ahead.
+                auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
+                auto bits = [](f16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(s16x2, v); };
+                f16x2 d_cur, e_cur, d_prev = zero_half;
+                auto pass1 = [&](int q, f16x2 &d, f16x2 &e) __attribute__((always_inline)) {
+                    d = hf(q == 0 ? diag0 : Hl[q - 1]) + hf(S[q]);
+                    e = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hf(El[q]) + e_half, hf(HOl[q])), zero_half);
+                    El[q] = bits(e);
+                };
+                f16x2 f = hf(fup0);
+                f16x2 ho = hf(up0) + o_half;
+                f16x2 h = zero_half;
+                f16x2 bestf = hf(best);
+                pass1(0, d_cur, e_cur);
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    f = __builtin_elementwise_maximum(f + e_half, ho);
+                    f16x2 d_next = zero_half, e_next = zero_half;
+                    if (q + 1 < K) pass1(q + 1, d_next, e_next);        // before Hl[q] is overwritten
+                    h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, e_cur), f);
+                    Hl[q] = bits(h);
+                    ho = h + o_half;
+                    HOl[q] = bits(ho);
+                    if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
+                    else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
+                    d_prev = d_cur;
+                    d_cur = d_next;
+                    e_cur = e_next;
+                }
+                best = bits(bestf);
+                h_last = bits(h);
+                f_last = bits(f);
+            } else if (SYM) {
                 // h = max(diag + S, max(left, up) - g): one subtract for both gap directions.  The chain
                 // max -> sub -> max down the column is strictly dependent; the next row's diag + S (which
                 // reads the OLD left value just before it is overwritten) and the maximum tracking are
@@ -598,7 +648,10 @@ score_kernel(const ScoreArgs args) {
 
     // ---- result ----
     s16x2 res;
-    if (ALG == kAlgSW) {
+    if (F16) {
+        const f16x2 b = __builtin_bit_cast(f16x2, best);
+        res = s16x2{(short)(int)b.x, (short)(int)b.y};
+    } else if (ALG == kAlgSW) {
         res = best;
     } else {
         // last column: every lane froze at column F-1; last row: last register of lane G-1

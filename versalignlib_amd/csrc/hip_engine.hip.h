@@ -45,7 +45,8 @@ inline void hip_check(hipError_t e, const char *what) {
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][4];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine]
+    const void *kernel[2][5];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
+                                   //                     symmetric affine on half floats (SW only)]
     const void *fill[2][4];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy]
 };
 
@@ -55,11 +56,12 @@ constexpr Geometry make_geometry() {
                     {{(const void *)&score_kernel<G, K, kAlgSW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>,
-                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>},
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSymF16>},
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
-                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>}},
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>, nullptr}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
@@ -316,10 +318,12 @@ public:
         a.open_ref = (short)sc_.open_ref;
         a.ext_ref = (short)sc_.ext_ref;
         int gaps;
-        if (sc_.affine)
+        if (sc_.affine) {
             gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
-        else
+            if (gaps == kGapAffineSym && alg == kAlgSW && !no_f16_ && half_float_exact(R, F)) gaps = kGapAffineSymF16;
+        } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
+        }
         const void *fn = plan.geo->kernel[alg][gaps];
         const int block_lds = plan.lds.total * plan.waves_per_block;
         if (block_lds > kDefaultBlockLds)
@@ -380,6 +384,24 @@ public:
                                       (size_t)long_lds, stream),
                       "hipLaunchKernel(score_long_kernel)");
         }
+    }
+
+    // what score_alignments computes in for this mode at the engine's full shape
+    const char *score_cell_format(int alg) const {
+        if (alg > 1) return "none";
+        if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
+        const bool sym_affine = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
+        if (!plan_.long_mode && sym_affine && alg == kAlgSW && !no_f16_ && half_float_exact(R_, F_)) return "f16";
+        return "int16";
+    }
+
+    // Smith-Waterman cells of an R x F sweep and everything added to them stay integers of magnitude
+    // <= 2048: exact in half floats (kGapAffineSymF16)
+    bool half_float_exact(int R, int F) const {
+        const long long top = (long long)std::min(R, F) * std::max({sc_.match, sc_.mismatch, 0});
+        const long long slack = std::max({std::abs(sc_.match), std::abs(sc_.mismatch), std::abs(sc_.open_read),
+                                          std::abs(sc_.ext_read), std::abs(sc_.open_ref), std::abs(sc_.ext_ref)});
+        return top + 2 * slack <= 2048 && slack <= 1024;
     }
 
     // int16 DP cells: the reference wraps silently.  Scores switch to int32 cells on the strip path
@@ -650,13 +672,14 @@ public:
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
                  "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-                 "\"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 "\"score_cells\": \"%s\", \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
                  plan_.long_mode ? 1 : 0, band_width_, ragged_, ragged_stats_.launches,
                  ragged_stats_.cells_padded > 0 ? ragged_stats_.cells_swept / ragged_stats_.cells_padded : 1.0,
-                 ragged_stats_.gather_ms, ragged_stats_.classify_ms, ragged_stats_.wait_ms, ragged_stats_.drain_ms);
+                 score_cell_format(opt & 0xF), ragged_stats_.gather_ms, ragged_stats_.classify_ms, ragged_stats_.wait_ms,
+                 ragged_stats_.drain_ms);
         return buf;
     }
 
@@ -1070,6 +1093,7 @@ private:
     bool slot_ragged_[kSlots] = {};
     RaggedStats ragged_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
+    bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     std::string arch_;
     LaunchPlan plan_;
     hipStream_t streams_[kSlots] = {};
