@@ -233,23 +233,45 @@ def main():
         alg_bytes = float(n) * (R + F + 2)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         d = eng.describe(0, n)
+        cells = d.get("score_cells", "int16")
+        pmc_key = "score_kernel<%d, %d, 0, %d>" % (d["group_lanes"], d["rows_per_lane"], 4 if cells == "f16" else 3)
+        cell_check = None
+        if cells == "f16":
+            # the half-float kernel must reproduce the int16 kernel bit for bit: check it on the whole
+            # batch (outside the timed region) and time the int16 variant beside it
+            os.environ["VALIGN_HIP_NO_F16"] = "1"
+            eng_i16 = hipkernel.Engine(R, F, affine_sc, device=local_rank)
+            del os.environ["VALIGN_HIP_NO_F16"]
+            ref_scores = eng_i16.score_device(0, reads, refs)
+            torch.cuda.synchronize()
+            i16_ms = kernel_launch_ms(eng_i16, 0, reads, refs, ref_scores.clone(), 5)
+            eng.score_device(0, reads, refs, local)
+            torch.cuda.synchronize()
+            cell_check = {"identical_to_int16_kernel": bool(torch.equal(local, ref_scores)),
+                          "int16_kernel_ms": round(i16_ms, 4),
+                          "int16_kernel_gcups": round(n * R * F / (i16_ms * 1e-3) / 1e9, 1),
+                          "note": "cells are integers of magnitude <= 2048: exact in fp16"}
+            eng_i16.close()
         line = {
             "metric": "GCUPS (giga DP cell updates/sec) SW affine-gap, 150x500 bp",
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "vs_baseline": None, "dtype": cells, "data": "synthetic",
             "config": {"workload": "%d pairs/GPU, 150 bp x 500 bp, SW affine-gap int16 score (open -5, extend -1), "
                                    "inputs resident in HBM%s" % (n, ", RCCL all-gather of scores" if world > 1 else ""),
                        "pairs_per_gpu": n, "read_length": R, "ref_length": F, "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": measured_traffic("score_kernel<%d, %d, 0, 3>" % (d["group_lanes"], d["rows_per_lane"]), n),
-                         "kernel": "score_kernel<%d,%d,SW,affine>" % (d["group_lanes"], d["rows_per_lane"]),
+                         "traffic": measured_traffic(pmc_key, n),
+                         "kernel": "score_kernel<%d,%d,SW,%s>" % (d["group_lanes"], d["rows_per_lane"],
+                                                                  "affine-f16" if d.get("score_cells") == "f16" else "affine"),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
                          "kernel_gcups": round(n * R * F / (k_ms * 1e-3) / 1e9, 1),
                          "note": "integer VALU bound: %.4f B/cell algorithmic, HBM is idle by design" % ((R + F + 2) / (R * F)),
-                         "valu": measured_valu_issue("score_kernel<%d, %d, 0, 3>" % (d["group_lanes"], d["rows_per_lane"]), n)},
+                         "valu": measured_valu_issue(pmc_key, n)},
         }
+        if cell_check is not None:
+            line["cell_check"] = cell_check
         lin_ms = kernel_launch_ms(eng_lin, 0, reads, refs, local, 5)
         line["linear_gap"] = {"kernel_ms": round(lin_ms, 4), "kernel_gcups": round(n * R * F / (lin_ms * 1e-3) / 1e9, 1),
                               "note": "reference's own gap model (bit-exact path), same batch"}

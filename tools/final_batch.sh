@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $R
 bash tools/pmc_passes.sh $TAG --modes sw_affine,sw_linear,nw_linear || exit 1
 python tools/pmc_summary.py $OUT/pmc_$TAG > $OUT/pmc_${TAG}_summary.json || exit 1
-cp $OUT/pmc_${TAG}_summary.json $R/profiles/r01_pmc_final.json
+cp $OUT/pmc_${TAG}_summary.json $R/profiles/r01_pmc_final.json   # bench.py reads traffic and VALU share from here
 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
 echo "bench done"
 export TMPDIR=/tmp
