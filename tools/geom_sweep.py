@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--F", type=int, default=500)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--geoms", default="0x0,8x20,16x10,16x12,32x8,64x12")
-    ap.add_argument("--affine", type=int, default=0)
+    ap.add_argument("--affine", type=int, default=0, help="1: open -5 / extend -1 both ways; 2: four different scores")
     ap.add_argument("--opt", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
     a = ap.parse_args()
@@ -30,7 +30,11 @@ def main():
     reads = torch.gather(refs, 1, cols)
     sub = torch.rand((a.n, a.R), device=dev, generator=g) < 0.15
     reads = torch.where(sub, lut[torch.randint(0, 4, (a.n, a.R), device=dev, generator=g)], reads).contiguous()
-    sc = hipkernel.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1) if a.affine else hipkernel.Scoring.make()
+    sc = hipkernel.Scoring.make()
+    if a.affine == 1:
+        sc = hipkernel.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1)
+    elif a.affine == 2:
+        sc = hipkernel.Scoring.make(2, -1, -3, -3, -5, -1, -4, -2)
     for geom in a.geoms.split(","):
         G, K = (int(x) for x in geom.split("x"))
         try:

@@ -389,6 +389,7 @@ constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_
 // whole cell at zero) and the maximum tracking two rows at a time: 8.5 instead of 10 packed
 // instructions per register.  The engine picks it when shape x scoring stays inside +-2048.
 constexpr int kGapAffineSymF16 = 4;
+constexpr int kGapAffineF16 = 5;      // half floats with four different open / extend scores: 9.5 instead of 11
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
 
@@ -396,7 +397,8 @@ template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
     using geo = Geo<G, K>;
-    constexpr bool F16 = GAPS == kGapAffineSymF16;
+    constexpr bool F16 = GAPS == kGapAffineSymF16 || GAPS == kGapAffineF16;
+    constexpr bool F16SYM = GAPS == kGapAffineSymF16;
     static_assert(!F16 || ALG == kAlgSW, "the half-float recurrence is Smith-Waterman only");
     constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym || F16;
     constexpr bool SYM = GAPS == kGapSym;
@@ -453,7 +455,9 @@ score_kernel(const ScoreArgs args) {
     const s16x2 border_f = pk(ALG == kAlgNW ? kNegInf : (short)0);
     // half-float recurrence: signed addends (open, extend <= 0)
     const _Float16 open_h = (_Float16)(int)args.open_ref, ext_h = (_Float16)(int)args.ext_ref;
+    const _Float16 open_rd = (_Float16)(int)args.open_read, ext_rd = (_Float16)(int)args.ext_read;
     const f16x2 o_half = f16x2{open_h, open_h}, e_half = f16x2{ext_h, ext_h}, zero_half = f16x2{(_Float16)0, (_Float16)0};
+    const f16x2 o_read_half = f16x2{open_rd, open_rd}, e_read_half = f16x2{ext_rd, ext_rd};
 
     // Hl: H of the previous column; El: E of the previous column; HOl (symmetric affine only):
     // H - open of the previous column, which feeds E of this column (and, within a column, F of
@@ -527,7 +531,8 @@ score_kernel(const ScoreArgs args) {
                 f16x2 d_cur, e_cur, d_prev = zero_half;
                 auto pass1 = [&](int q, f16x2 &d, f16x2 &e) __attribute__((always_inline)) {
                     d = hf(q == 0 ? diag0 : Hl[q - 1]) + hf(S[q]);
-                    e = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hf(El[q]) + e_half, hf(HOl[q])), zero_half);
+                    const f16x2 e_open = F16SYM ? hf(HOl[q]) : hf(Hl[q]) + o_read_half;
+                    e = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hf(El[q]) + e_read_half, e_open), zero_half);
                     El[q] = bits(e);
                 };
                 f16x2 f = hf(fup0);
@@ -543,7 +548,7 @@ score_kernel(const ScoreArgs args) {
                     h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, e_cur), f);
                     Hl[q] = bits(h);
                     ho = h + o_half;
-                    HOl[q] = bits(ho);
+                    if (F16SYM) HOl[q] = bits(ho);
                     if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
                     else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
                     d_prev = d_cur;

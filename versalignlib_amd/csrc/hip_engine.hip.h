@@ -45,8 +45,8 @@ inline void hip_check(hipError_t e, const char *what) {
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][5];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
-                                   //                     symmetric affine on half floats (SW only)]
+    const void *kernel[2][6];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
+                                   //                     symmetric affine / affine on half floats (SW only)]
     const void *fill[2][4];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy]
 };
 
@@ -57,11 +57,12 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgSW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>,
-                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSymF16>},
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSymF16>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineF16>},
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
-                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>, nullptr}},
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>, nullptr, nullptr}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
@@ -320,7 +321,7 @@ public:
         int gaps;
         if (sc_.affine) {
             gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
-            if (gaps == kGapAffineSym && alg == kAlgSW && !no_f16_ && half_float_exact(R, F)) gaps = kGapAffineSymF16;
+            if (alg == kAlgSW && !no_f16_ && half_float_exact(R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
         }
@@ -390,8 +391,7 @@ public:
     const char *score_cell_format(int alg) const {
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
-        const bool sym_affine = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
-        if (!plan_.long_mode && sym_affine && alg == kAlgSW && !no_f16_ && half_float_exact(R_, F_)) return "f16";
+        if (!plan_.long_mode && sc_.affine && alg == kAlgSW && !no_f16_ && half_float_exact(R_, F_)) return "f16";
         return "int16";
     }
 
