@@ -166,8 +166,12 @@ score_long_kernel(const LongArgs args) {
             up0 = ops::from_bits(__builtin_nontemporal_load(brow_prev + brow_slot * args.row_dwords + (c_lo - 1)));
         int j = c_lo - l;
 
-        auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        // TRACK: how the step feeds the running SW maximum (see score_kernel): every diag + S, or, for
+        // the shared-gap recurrence in the unmasked step pairs, nothing in the first step and every
+        // max(left, up) plus the last row in the second.
+        auto step = [&](auto masked_tag, auto track_tag, int t) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked_tag)::value;
+            constexpr int TRACK = decltype(track_tag)::value;
             const cell_t diag0 = up0;
             // row above: previous lane of the group; for the first lane the previous strip's bottom row
             const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
@@ -199,11 +203,14 @@ score_long_kernel(const LongArgs args) {
                         cell_t d_next = ops::bc(0);
                         if (q + 1 < K) d_next = Hl[q] + S[q + 1];
                         const cell_t y = (ALG == kAlgSW) ? ops::sub0(x, g_ref) : x + g_ref;
-                        if (ALG == kAlgSW) best = ops::mx(best, d_cur);
+                        if (ALG == kAlgSW && TRACK == kTrackAll) best = ops::mx(best, d_cur);
+                        if (ALG == kAlgSW && TRACK == kTrackPair) best = ops::mx(best, x);
                         h = ops::mx(d_cur, y);
                         Hl[q] = h;
                         d_cur = d_next;
+                        __builtin_amdgcn_sched_barrier(0);      // keep the interleaving: the scheduler regroups it otherwise
                     }
+                    if (ALG == kAlgSW && TRACK == kTrackPair) best = ops::mx(best, h);
                 } else {
                     auto pass1 = [&](int q) __attribute__((always_inline)) -> cell_t {
                         const cell_t d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
@@ -267,15 +274,18 @@ score_long_kernel(const LongArgs args) {
             }
             __syncthreads();
             const int t1 = t0 + kPhase < steps ? t0 + kPhase : steps;
+            using all_t = std::integral_constant<int, kTrackAll>;
+            using first_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackNone : kTrackAll>;
+            using second_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackPair : kTrackAll>;
             if (t0 >= G - 1 && t1 <= ncols) {
                 int t = t0;
                 for (; t + 1 < t1; t += 2) {        // two steps per trip (loop-carried registers swap roles)
-                    step(std::false_type{}, t);
-                    step(std::false_type{}, t + 1);
+                    step(std::false_type{}, first_t{}, t);
+                    step(std::false_type{}, second_t{}, t + 1);
                 }
-                for (; t < t1; ++t) step(std::false_type{}, t);
+                for (; t < t1; ++t) step(std::false_type{}, all_t{}, t);
             } else {
-                for (int t = t0; t < t1; ++t) step(std::true_type{}, t);
+                for (int t = t0; t < t1; ++t) step(std::true_type{}, all_t{}, t);
             }
         }
         // ---- drain the last two phases of the outgoing row ----
