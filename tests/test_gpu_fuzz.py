@@ -1,0 +1,82 @@
+"""Seeded differential sweep over shapes and scoring parameters: scores and alignments of
+libHIPKernel.so against the oracle, bit-exact, for combinations no hand-written case names (zero and
+equal gap scores, zero mismatch, large matches, tiny and lopsided shapes, every affine variant, both
+traceback policies).  Deterministic: the configurations come from splitmix64."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+from versalignlib_amd import hipkernel, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(case):
+    """Configuration number `case` -> dict (pure function of the case number)."""
+    r = synth._stream(9000 + case, 1, (16,))
+    pick = lambda k, lo, hi: int(lo + int(r[k] % np.uint64(hi - lo + 1)))       # noqa: E731
+    shape_kind = pick(0, 0, 3)
+    if shape_kind == 0:
+        R, F = pick(1, 1, 40), pick(2, 1, 60)
+    elif shape_kind == 1:
+        R, F = pick(1, 30, 200), pick(2, 100, 600)
+    elif shape_kind == 2:
+        R, F = pick(1, 100, 320), pick(2, 1, 90)           # read longer than ref
+    else:
+        R, F = pick(1, 140, 160), pick(2, 480, 520)          # around the headline shape
+    match = pick(3, 0, 6) if pick(15, 0, 5) else pick(3, 7, 14)      # now and then around the half-float limit
+    mismatch = -pick(4, 0, 5)
+    gap_read, gap_ref = -pick(5, 0, 7), -pick(6, 0, 7)
+    if pick(7, 0, 2) == 0:
+        gap_ref = gap_read
+    affine = None
+    kind = pick(8, 0, 3)
+    if kind == 1:                                            # symmetric affine
+        o, e = -pick(9, 0, 9), -pick(10, 0, 4)
+        affine = (o, e, o, e)
+    elif kind == 2:                                          # four different scores
+        affine = (-pick(9, 0, 9), -pick(10, 0, 4), -pick(11, 0, 9), -pick(12, 0, 4))
+    n = pick(13, 1, 400)
+    return dict(R=R, F=F, n=n, match=match, mismatch=mismatch, gap_read=gap_read, gap_ref=gap_ref,
+                affine=affine, seed=100 + case, sse=(kind == 3 and pick(14, 0, 1) == 1))
+
+
+def _scorings(c):
+    if c["affine"]:
+        o_r, e_r, o_f, e_f = c["affine"]
+        kw = dict(open_read=o_r, ext_read=e_r, open_ref=o_f, ext_ref=e_f)
+    else:
+        kw = {}
+    args = (c["match"], c["mismatch"], c["gap_read"], c["gap_ref"])
+    return cpu_ref.Scoring.make(*args, **kw), hipkernel.Scoring.make(*args, **kw)
+
+
+@pytest.mark.parametrize("case", range(240))
+def test_random_configuration(case):
+    import torch
+    c = _draw(case)
+    R, F, n = c["R"], c["F"], c["n"]
+    reads, refs = synth.make_pairs(n, R, F, seed=c["seed"], indel_rate=0.03, n_run_frac=0.05, short_frac=0.1,
+                                   lowercase_frac=0.03, junk_frac=0.03)
+    osc, hsc = _scorings(c)
+    affine = c["affine"] is not None
+    eng = hipkernel.Engine(R, F, hsc)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    for opt in (host.SW, host.NW):
+        got = eng.score_device(opt, d_reads, d_refs).cpu().numpy()
+        exp = cpu_ref.score(opt, reads, refs, osc, threads=8, affine=affine)
+        assert np.array_equal(got, exp), (c, "score", opt, np.nonzero(got != exp)[0][:6])
+        host_got = eng.score_host(opt, reads, refs, threads=2)
+        assert np.array_equal(host_got, exp), (c, "score_host", opt)
+    policy = "sse" if (c["sse"] and not affine) else "default"
+    if policy == "sse":
+        eng.set_traceback_policy(1)
+    for opt in (host.SW, host.NW):
+        rows, idx = eng.align_device(opt, d_reads, d_refs)
+        rows, idx = rows.cpu().numpy(), idx.cpu().numpy()
+        erows, eidx = cpu_ref.align(opt, reads, refs, osc, threads=8, affine=affine, policy=policy)
+        bad = np.nonzero((idx != eidx).any(axis=1))[0]
+        assert bad.size == 0, (c, "idx", opt, bad[:5], idx[bad[:2]], eidx[bad[:2]])
+        bad = np.nonzero((rows != erows).any(axis=(1, 2)))[0]
+        assert bad.size == 0, (c, "rows", opt, bad[:5])
+    eng.close()
