@@ -383,11 +383,12 @@ constexpr int kGapLinear = 0;
 constexpr int kGapSym = 1;
 constexpr int kGapAffine = 2;
 constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_read == ext_ref
-// The same recurrence as kGapAffineSym for Smith-Waterman on packed half floats: every value is an
+// The same recurrence as kGapAffineSym on packed half floats: every value is an
 // integer of magnitude <= 2048, which fp16 represents exactly, and gfx950's v_pk_maximum3_f16
 // takes three operands -- h = max3(diag + S, E, F), E = max3(E - ext, H - open, 0) (which floors the
-// whole cell at zero) and the maximum tracking two rows at a time: 8.5 instead of 10 packed
-// instructions per register.  The engine picks it when shape x scoring stays inside +-2048.
+// whole SW cell at zero) and the SW maximum tracking two rows at a time: 8.5 instead of 10 packed
+// instructions per register (NW variant: 8 instead of 9, gap matrices start at a real -inf).  The
+// engine picks it when shape x scoring stays inside +-2048.
 constexpr int kGapAffineSymF16 = 4;
 constexpr int kGapAffineF16 = 5;      // half floats with four different open / extend scores: 9.5 instead of 11
 
@@ -399,7 +400,6 @@ score_kernel(const ScoreArgs args) {
     using geo = Geo<G, K>;
     constexpr bool F16 = GAPS == kGapAffineSymF16 || GAPS == kGapAffineF16;
     constexpr bool F16SYM = GAPS == kGapAffineSymF16;
-    static_assert(!F16 || ALG == kAlgSW, "the half-float recurrence is Smith-Waterman only");
     constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym || F16;
     constexpr bool SYM = GAPS == kGapSym;
     constexpr bool AFFSYM = GAPS == kGapAffineSym;
@@ -452,7 +452,8 @@ score_kernel(const ScoreArgs args) {
         o_read = pk(args.open_read);  e_read = pk(args.ext_read);
         o_ref = pk(args.open_ref);    e_ref = pk(args.ext_ref);
     }
-    const s16x2 border_f = pk(ALG == kAlgNW ? kNegInf : (short)0);
+    // gap matrices start at minus infinity in the NW variant (half floats have the real thing: 0xFC00)
+    const s16x2 border_f = pk(ALG == kAlgNW ? (F16 ? (short)0xFC00 : kNegInf) : (short)0);
     // half-float recurrence: signed addends (open, extend <= 0)
     const _Float16 open_h = (_Float16)(int)args.open_ref, ext_h = (_Float16)(int)args.ext_ref;
     const _Float16 open_rd = (_Float16)(int)args.open_read, ext_rd = (_Float16)(int)args.ext_read;
@@ -463,7 +464,8 @@ score_kernel(const ScoreArgs args) {
     // H - open of the previous column, which feeds E of this column (and, within a column, F of
     // the next row), so the subtract is done once per cell instead of twice.
     s16x2 Hl[K], El[K], HOl[K];
-    const s16x2 ho_border = (ALG == kAlgSW) ? pk(0) : o_ref;      // border H (= 0) minus open
+    const s16x2 ho_border = (ALG == kAlgSW) ? pk(0)               // border H (= 0) minus open
+                                            : (F16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.open_ref)) : o_ref);
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         Hl[q] = pk(0);
@@ -532,7 +534,8 @@ score_kernel(const ScoreArgs args) {
                 auto pass1 = [&](int q, f16x2 &d, f16x2 &e) __attribute__((always_inline)) {
                     d = hf(q == 0 ? diag0 : Hl[q - 1]) + hf(S[q]);
                     const f16x2 e_open = F16SYM ? hf(HOl[q]) : hf(Hl[q]) + o_read_half;
-                    e = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hf(El[q]) + e_read_half, e_open), zero_half);
+                    e = __builtin_elementwise_maximum(hf(El[q]) + e_read_half, e_open);
+                    if (ALG == kAlgSW) e = __builtin_elementwise_maximum(e, zero_half);     // folds into one max3: floors the cell
                     El[q] = bits(e);
                 };
                 f16x2 f = hf(fup0);
@@ -549,8 +552,10 @@ score_kernel(const ScoreArgs args) {
                     Hl[q] = bits(h);
                     ho = h + o_half;
                     if (F16SYM) HOl[q] = bits(ho);
-                    if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
-                    else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
+                    if (ALG == kAlgSW) {
+                        if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
+                        else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
+                    }
                     d_prev = d_cur;
                     d_cur = d_next;
                     e_cur = e_next;
@@ -628,7 +633,11 @@ score_kernel(const ScoreArgs args) {
                 h_last = h;
                 f_last = f;
             }
-            if (ALG == kAlgNW) row_best = pk_max(row_best, h_last);
+            if (ALG == kAlgNW) {
+                if (F16) row_best = __builtin_bit_cast(s16x2, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, row_best),
+                                                                                             __builtin_bit_cast(f16x2, h_last)));
+                else row_best = pk_max(row_best, h_last);
+            }
         }
         ++j;
         code_addr += 2;
@@ -654,7 +663,13 @@ score_kernel(const ScoreArgs args) {
     // ---- result ----
     s16x2 res;
     if (F16) {
-        const f16x2 b = __builtin_bit_cast(f16x2, best);
+        f16x2 b = __builtin_bit_cast(f16x2, best);
+        if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column)
+            b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk(0));
+#pragma unroll
+            for (int q = 0; q < K; ++q) b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, Hl[q]));
+            b = __builtin_elementwise_maximum(b, f16x2{(_Float16)0, (_Float16)0});
+        }
         res = s16x2{(short)(int)b.x, (short)(int)b.y};
     } else if (ALG == kAlgSW) {
         res = best;

@@ -62,7 +62,9 @@ constexpr Geometry make_geometry() {
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
-                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>, nullptr, nullptr}},
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSymF16>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
@@ -321,7 +323,7 @@ public:
         int gaps;
         if (sc_.affine) {
             gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
-            if (alg == kAlgSW && !no_f16_ && half_float_exact(R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
+            if (!no_f16_ && half_float_exact(alg, R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
         }
@@ -391,17 +393,19 @@ public:
     const char *score_cell_format(int alg) const {
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
-        if (!plan_.long_mode && sc_.affine && alg == kAlgSW && !no_f16_ && half_float_exact(R_, F_)) return "f16";
+        if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_)) return "f16";
         return "int16";
     }
 
-    // Smith-Waterman cells of an R x F sweep and everything added to them stay integers of magnitude
-    // <= 2048: exact in half floats (kGapAffineSymF16)
-    bool half_float_exact(int R, int F) const {
+    // Every cell of an R x F sweep and everything added to it stays an integer of magnitude <= 2048:
+    // exact in half floats (kGapAffineSymF16 / kGapAffineF16).  SW cells are >= 0; cells of the NW
+    // variant are bounded below by the cheaper border path (as in check_int16_range).
+    bool half_float_exact(int alg, int R, int F) const {
         const long long top = (long long)std::min(R, F) * std::max({sc_.match, sc_.mismatch, 0});
         const long long slack = std::max({std::abs(sc_.match), std::abs(sc_.mismatch), std::abs(sc_.open_read),
                                           std::abs(sc_.ext_read), std::abs(sc_.open_ref), std::abs(sc_.ext_ref)});
-        return top + 2 * slack <= 2048 && slack <= 1024;
+        const long long bottom = alg == kAlgSW ? 0 : (long long)(std::min(R, F) + 2) * slack;
+        return top + 2 * slack <= 2048 && bottom + 2 * slack <= 2048 && slack <= 1024;
     }
 
     // int16 DP cells: the reference wraps silently.  Scores switch to int32 cells on the strip path
