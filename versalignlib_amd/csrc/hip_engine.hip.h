@@ -24,8 +24,7 @@
 #include <thread>
 #include <vector>
 
-#include "dp_kernels.hip.h"
-#include "trace_kernels.hip.h"
+#include "kernel_instances.hip.h"
 #include "long_kernels.hip.h"
 
 namespace valign {
@@ -41,7 +40,12 @@ inline void hip_check(hipError_t e, const char *what) {
         throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// One compiled (G, K) geometry with its four kernel variants.
+// The per-geometry kernels are compiled in kernel_part.hip (one object per part, in parallel)
+#define VALIGN_DECLARE(G, K) VALIGN_GEOMETRY_KERNELS(extern template, G, K)
+VALIGN_ALL_GEOMETRIES(VALIGN_DECLARE)
+#undef VALIGN_DECLARE
+
+// One compiled (G, K) geometry with its kernel variants.
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
@@ -80,6 +84,9 @@ static const Geometry kGeometries[] = {
     make_geometry<64, 32>(),
 };
 constexpr int kNumGeometries = sizeof(kGeometries) / sizeof(kGeometries[0]);
+#define VALIGN_COUNT(G, K) +1
+static_assert(kNumGeometries == 0 VALIGN_ALL_GEOMETRIES(VALIGN_COUNT), "kernel_instances.hip.h lists other geometries than this table");
+#undef VALIGN_COUNT
 
 constexpr int kMaxBlockLds = 160 * 1024;       // gfx950: 160 KiB per CU, one block may take it all
 constexpr int kSlots = 4;                      // staging slots of the host-pointer pipeline

@@ -620,6 +620,7 @@ struct TraceArgs {
 
 typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
 
+#ifndef VALIGN_KERNEL_PART_TU      // not a template: defined once, in the plugin's main translation unit
 // One lane per pair.  The walk is a chain of dependent loads, so the kernel is bound by the
 // number of memory transactions: pointer words are fetched 16 bytes (4 rows x 8 columns) at a
 // time, read/ref bases 4 at a time, and the two output rows are written as dwords.
@@ -760,5 +761,6 @@ traceback_kernel(const TraceArgs a) {
     out[2] = (short)(k + 1);
     out[3] = (short)(AL - 1);
 }
+#endif
 
 }  // namespace valign
