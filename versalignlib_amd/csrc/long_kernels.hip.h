@@ -25,6 +25,7 @@ namespace valign {
 
 constexpr int kPhase = 64;                 // steps between ring refills; must be >= G - 1
 constexpr int kRing = 2 * kPhase;          // ring slots per lane group
+constexpr int kLead = 8;                   // columns the ring refill runs ahead of the phase (the sweep prefetches two)
 
 struct LongArgs {
     const uint8_t *reads;
@@ -130,6 +131,8 @@ score_long_kernel(const LongArgs args) {
 
     for (int i = lane; i < geo::kPairStride / 4; i += kWave)
         reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
+    // the sweep prefetches profile rows through whatever slab numbers the ring holds: start with valid ones
+    for (int i = lane; i < geo::kGroups * kRing * 2; i += kWave) codes[i] = (unsigned char)geo::kZeroSlab;
 
     for (int s = 0; s < args.strips; ++s) {
         // ---- query profile of this strip's rows ----
@@ -165,6 +168,8 @@ score_long_kernel(const LongArgs args) {
         if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
             up0 = ops::from_bits(__builtin_nontemporal_load(brow_prev + brow_slot * args.row_dwords + (c_lo - 1)));
         int j = c_lo - l;
+        unsigned pa[K / 2], pb[K / 2];            // raw profile dwords of the coming step (LDS pipeline)
+        unsigned ca_next = 0, cb_next = 0;        // slab numbers of the step after
 
         // TRACK: how the step feeds the running SW maximum (see score_kernel): every diag + S, or, for
         // the shared-gap recurrence in the unmasked step pairs, nothing in the first step and every
@@ -177,21 +182,28 @@ score_long_kernel(const LongArgs args) {
             const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
             const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
             up0 = ops::from_bits(l == 0 ? from_ring : from_lane);
-            if (!MASKED || (unsigned)(j - c_lo) < (unsigned)ncols) {
-                const unsigned ca_addr = codes_base + ((j & (kRing - 1)) << 1);
-                const unsigned ca = *(lds_cu8 *)(ca_addr), cb = *(lds_cu8 *)(ca_addr + 1);
-                cell_t S[K];
-                if constexpr (WIDE) {
-                    unsigned raw[K / 2];
-                    lds_load_lane<K>(lane_base + (half ? cb : ca) * geo::kPairStride, raw);
+            // LDS fetches run ahead of the arithmetic (every lane, every step): the raw profile dwords of
+            // this step are in registers, the rows of step t+1 and the slab numbers of step t+2 are
+            // requested now.  The ring refill leads the phase by kLead columns for that.
+            cell_t S[K];
+            if constexpr (WIDE) {
 #pragma unroll
-                    for (int c = 0; c < K / 2; ++c) {
-                        S[2 * c] = (int)(short)(raw[c] & 0xFFFFu);
-                        S[2 * c + 1] = (int)raw[c] >> 16;
-                    }
-                } else {
-                    fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+                for (int c = 0; c < K / 2; ++c) {
+                    S[2 * c] = (int)(short)(pa[c] & 0xFFFFu);
+                    S[2 * c + 1] = (int)pa[c] >> 16;
                 }
+                lds_load_lane<K>(lane_base + (half ? cb_next : ca_next) * geo::kPairStride, pa);
+            } else {
+                merge_profile<K>(pa, pb, S);
+                lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
+                lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+            }
+            {
+                const unsigned next_addr = codes_base + (((j + 2) & (kRing - 1)) << 1);
+                ca_next = *(lds_cu8 *)(next_addr);
+                cb_next = *(lds_cu8 *)(next_addr + 1);
+            }
+            if (!MASKED || (unsigned)(j - c_lo) < (unsigned)ncols) {
                 // column-independent work of row q+1 sits between the links of the dependent chain of
                 // row q (see score_kernel)
                 cell_t h = up0;
@@ -238,41 +250,87 @@ score_long_kernel(const LongArgs args) {
             ++j;
         };
 
-        for (int t0 = 0; t0 < steps; t0 += kPhase) {
-            // ---- ring refill for columns [c_lo + t0, c_lo + t0 + kPhase) ----
+        // ---- ring refill, software pipelined ----
+        // The reference bases and the previous strip's boundary values of phase p+1 are requested
+        // from HBM/L2 when phase p starts computing (prefetch: global -> registers) and reach the
+        // LDS rings when it is done (commit): a wave never waits for its own refill, which cost a
+        // third of the cycles when the loads were issued and consumed in one go.
+        unsigned char pre_base[8];
+        u32x4 pre_brow = {0u, 0u, 0u, 0u};
+        bool pre_brow_valid = false;
+        auto prefetch = [&](int t0) __attribute__((always_inline)) {
+            const int p = lane / 8, c0 = c_lo + kLead + t0 + (lane % 8) * 8;  // lane -> pair lane/8, eight columns
+            const int ps = p > last ? last : p;
+            const uint8_t *src = args.refs + (pair0 + ps) * F;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) pre_base[x] = (c0 + x < F) ? src[c0 + x] : (unsigned char)0;
+            const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;   // lane -> group lane/16, four columns
+            pre_brow_valid = s > 0 && col + 4 <= args.row_dwords;
+            if (pre_brow_valid)         // L2-served load: the same addresses were read two strips ago and rewritten since
+                pre_brow = __builtin_nontemporal_load(
+                    reinterpret_cast<const u32x4 *>(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + col));
+        };
+        auto commit = [&](int t0) __attribute__((always_inline)) {
             {
-                // class codes: lane -> pair lane/8, eight columns
-                const int p = lane / 8, c0 = c_lo + t0 + (lane % 8) * 8;
-                const int ps = p > last ? last : p;
-                const uint8_t *src = args.refs + (pair0 + ps) * F;
+                const int p = lane / 8, c0 = c_lo + kLead + t0 + (lane % 8) * 8;
                 unsigned char *dst = codes + (p / 2) * (kRing * 2) + (p & 1);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) {
                     const int col = c0 + x;
-                    const int c = col < F ? base_class(src[col]) : 0;
+                    const int c = col < F ? base_class(pre_base[x]) : 0;
                     dst[(col & (kRing - 1)) * 2] =
                         (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
                 }
-                // boundary values: lane -> group lane/16, four columns
-                const int g = lane / 16, col = c_lo + t0 + (lane % 16) * 4;
+                const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (s > 0 && col + 4 <= args.row_dwords) {
-                    // L2-served load: the same addresses were read two strips ago and rewritten since
-                    const u32x4 raw = __builtin_nontemporal_load(
-                        reinterpret_cast<const u32x4 *>(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + col));
-                    v.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? raw.x : 0u;      // outside the previous strip's
-                    v.y = (col + 1 >= p_lo && col + 1 <= p_hi) ? raw.y : 0u;      // columns the row above is 0
-                    v.z = (col + 2 >= p_lo && col + 2 <= p_hi) ? raw.z : 0u;
-                    v.w = (col + 3 >= p_lo && col + 3 <= p_hi) ? raw.w : 0u;
+                if (pre_brow_valid) {
+                    v.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? pre_brow.x : 0u;      // outside the previous strip's
+                    v.y = (col + 1 >= p_lo && col + 1 <= p_hi) ? pre_brow.y : 0u;      // columns the row above is 0
+                    v.z = (col + 2 >= p_lo && col + 2 <= p_hi) ? pre_brow.z : 0u;
+                    v.w = (col + 3 >= p_lo && col + 3 <= p_hi) ? pre_brow.w : 0u;
                 }
                 *reinterpret_cast<uint4 *>(ring_in + g * kRing + (col & (kRing - 1))) = v;
                 if (t0 >= 2 * kPhase && s + 1 < args.strips) {           // drain what lane G-1 finished two phases ago
-                    const int oc = col - 2 * kPhase;
+                    const int oc = col - kLead - 2 * kPhase;
                     *reinterpret_cast<uint4 *>(brow_cur + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
                 }
             }
+        };
+        // head of the strip: the first kLead columns go in directly (one column per lane), then the
+        // sweep's own pipeline is primed with the slab numbers / profile rows of steps 0 and 1
+        {
+            const int p = lane / 8, col = c_lo + (lane % 8);
+            const int ps = p > last ? last : p;
+            const int c = col < F ? base_class(args.refs[(pair0 + ps) * F + col]) : 0;
+            codes[(p / 2) * (kRing * 2) + (p & 1) + (col & (kRing - 1)) * 2] =
+                (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+            if (lane < geo::kGroups * kLead) {
+                const int g = lane / kLead, bc = c_lo + (lane % kLead);
+                unsigned v = 0u;
+                if (s > 0 && bc < args.row_dwords && bc >= p_lo && bc <= p_hi)
+                    v = __builtin_nontemporal_load(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + bc);
+                ring_in[g * kRing + (bc & (kRing - 1))] = v;
+            }
+        }
+        prefetch(0);
+        for (int t0 = 0; t0 < steps; t0 += kPhase) {
+            commit(t0);
+            if (t0 == 0) {
+                __syncthreads();
+                const unsigned a0 = codes_base + ((j & (kRing - 1)) << 1), a1 = codes_base + (((j + 1) & (kRing - 1)) << 1);
+                const unsigned ca = *(lds_cu8 *)(a0), cb = *(lds_cu8 *)(a0 + 1);
+                if constexpr (WIDE) {
+                    lds_load_lane<K>(lane_base + (half ? cb : ca) * geo::kPairStride, pa);
+                } else {
+                    lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+                    lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+                }
+                ca_next = *(lds_cu8 *)(a1);
+                cb_next = *(lds_cu8 *)(a1 + 1);
+            }
             __syncthreads();
+            if (t0 + kPhase < steps) prefetch(t0 + kPhase);
             const int t1 = t0 + kPhase < steps ? t0 + kPhase : steps;
             using all_t = std::integral_constant<int, kTrackAll>;
             using first_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackNone : kTrackAll>;
