@@ -53,10 +53,12 @@ def main():
             k.compute_alignments(0, reads[:n], refs[:n], normalise=False)
             sec = time.perf_counter() - t0
         inside = k.last_call_seconds()
+        phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
         print(json.dumps({"call": "compute_alignments(SW) via ABI, 2n new[] rows", "pairs": n,
                           "seconds_in_plugin": round(inside, 4),
                           "gcups_pcie_inclusive": round(synth.gcups(n, R, F, inside), 1),
-                          "seconds_with_harness_copy_out": round(sec, 4)}))
+                          "seconds_with_harness_copy_out": round(sec, 4),
+                          "host_phases": phases[-1].split("host phases ")[-1] if phases else None}))
 
 
 if __name__ == "__main__":

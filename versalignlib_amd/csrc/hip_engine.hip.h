@@ -226,7 +226,11 @@ public:
         plan_ = choose_plan(R_, F_, force_g, force_k);
         build_length_classes();
         for (int s = 0; s < kSlots; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
-        for (int s = 0; s < kSlots; ++s) hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
+        for (int s = 0; s < kSlots; ++s) {
+            hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&in_done_[s], hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&kernels_done_[s], hipEventDisableTiming), "hipEventCreate");
+        }
     }
 
     ~Engine() {
@@ -236,6 +240,8 @@ public:
         if (d_brow_) (void)hipFree(d_brow_);
         for (int s = 0; s < kSlots; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
+            if (in_done_[s]) (void)hipEventDestroy(in_done_[s]);
+            if (kernels_done_[s]) (void)hipEventDestroy(kernels_done_[s]);
             if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
         }
     }
@@ -633,6 +639,11 @@ public:
 
     // Host pointers in, Alignment[] out: the rows of every pair are fresh operator new[] blocks
     // (the host's ~Alignment delete[]s them, include/AlignmentKernel.h:20-23).
+    // Host pointers in, Alignment[] out.  Three streams: copy-in (H2D), kernels (fill + traceback; they
+    // share the pointer scratch, so one stream), copy-out (D2H), chained per chunk with events, over
+    // kSlots staging slots -- the 1.3 KB/pair result copy of chunk c, the kernels of chunk c+1 and the
+    // input copy of chunk c+2 overlap, and the host gathers / scatters (2n operator new[] blocks, which
+    // the ABI demands) meanwhile.
     template <typename AlignmentT>
     void align_host(int opt, int n, const char *const *reads, const char *const *refs, AlignmentT *alignments,
                     int threads) {
@@ -641,38 +652,60 @@ public:
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const int AL = R_ + F_;
         const size_t per_pair = (size_t)3 * AL + 8;
-        long long chunk = per_pair ? (long long)((256u << 20) / per_pair) : n;
+        long long chunk = per_pair ? (long long)(align_chunk_bytes_ / per_pair) : n;
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
         ensure_staging(chunk);
         ensure_align_staging(chunk);
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
+        hipStream_t kernels = streams_[0], copy_in = streams_[1], copy_out = streams_[2];
+        ragged_stats_ = RaggedStats{};
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
+            const auto t0 = std::chrono::steady_clock::now();
             scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
+            ragged_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
             slot_pending_[s] = 0;
         };
         int slot = 0;
-        for (long long begin = 0; begin < n; begin += chunk, slot ^= 1) {
+        for (long long begin = 0; begin < n; begin += chunk, slot = (slot + 1) % kSlots) {
             const long long cnt = std::min<long long>(chunk, n - begin);
-            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
+            auto t0 = std::chrono::steady_clock::now();
+            hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");   // its last chunk is back on the host
+            ragged_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(slot);
+            t0 = std::chrono::steady_clock::now();
             gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
-            hipStream_t st = streams_[0];          // one stream: the pointer scratch is shared
-            hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
-            hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
-            align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], st);
-            hip_check(hipMemcpyAsync(h_rows_[slot], d_rows_[slot], (size_t)cnt * 2 * AL, hipMemcpyDeviceToHost, st), "D2H rows");
-            hip_check(hipMemcpyAsync(h_idx_[slot], d_idx_[slot], sizeof(short) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H idx");
-            hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
+            ragged_stats_.gather_ms += ms_between(t0, std::chrono::steady_clock::now());
+            hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, copy_in), "H2D reads");
+            hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, copy_in), "H2D refs");
+            hip_check(hipEventRecord(in_done_[slot], copy_in), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(kernels, in_done_[slot], 0), "hipStreamWaitEvent");
+            align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], kernels);
+            hip_check(hipEventRecord(kernels_done_[slot], kernels), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(copy_out, kernels_done_[slot], 0), "hipStreamWaitEvent");
+            hip_check(hipMemcpyAsync(h_rows_[slot], d_rows_[slot], (size_t)cnt * 2 * AL, hipMemcpyDeviceToHost, copy_out), "D2H rows");
+            hip_check(hipMemcpyAsync(h_idx_[slot], d_idx_[slot], sizeof(short) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, copy_out), "D2H idx");
+            hip_check(hipEventRecord(slot_done_[slot], copy_out), "hipEventRecord");
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;
         }
-        for (int s = 0; s < 2; ++s) {
+        for (int k = 0; k < kSlots; ++k) {              // oldest chunk first
+            const int s = (slot + k) % kSlots;
+            const auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
+            ragged_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(s);
         }
+    }
+
+    // host-side phases of the last score_host / align_host call
+    std::string host_phases() const {
+        char buf[200];
+        snprintf(buf, sizeof buf, "{\"host_gather_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 ragged_stats_.gather_ms, ragged_stats_.wait_ms, ragged_stats_.drain_ms);
+        return buf;
     }
 
     std::string describe(int opt, long long n) const {
@@ -778,7 +811,7 @@ private:
         d_ptr_ = nullptr;
         d_ends_ = nullptr;
         trace_pairs_ = 0;
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < kSlots; ++s) {
             if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
             if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
             if (d_rows_[s]) (void)hipFree(d_rows_[s]);
@@ -808,7 +841,7 @@ private:
     void ensure_align_staging(long long pairs) {
         if (pairs <= align_staged_pairs_) return;
         const size_t AL = (size_t)R_ + F_;
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < kSlots; ++s) {
             if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
             if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
             if (d_rows_[s]) (void)hipFree(d_rows_[s]);
@@ -923,6 +956,7 @@ private:
         }
         if (const char *m = getenv("VALIGN_HIP_RAGGED_MIN")) ragged_min_ = std::max(1, atoi(m));   // tuning switch
         if (const char *m = getenv("VALIGN_HIP_CHUNK_BYTES")) score_chunk_bytes_ = (size_t)std::max(4096ll, atoll(m));
+        if (const char *m = getenv("VALIGN_HIP_ALIGN_CHUNK_BYTES")) align_chunk_bytes_ = (size_t)std::max(4096ll, atoll(m));
     }
 
     const LaunchPlan &class_plan(int R, int F) {
@@ -1093,6 +1127,7 @@ private:
     int score_width_ = 0;
     int ragged_ = 1, force_g_ = 0, force_k_ = 0;
     size_t score_chunk_bytes_ = 48u << 20;                   // staging chunk of score_host (VALIGN_HIP_CHUNK_BYTES)
+    size_t align_chunk_bytes_ = 128u << 20;                  // staging chunk of align_host, inputs + results (VALIGN_HIP_ALIGN_CHUNK_BYTES)
     long long ragged_min_ = 2048;                             // pairs a length bin needs for its own launch
     std::vector<int> read_caps_, ref_caps_;
     std::vector<unsigned char> read_class_;
@@ -1121,8 +1156,9 @@ private:
     unsigned *d_ptr_ = nullptr;
     EndCell *d_ends_ = nullptr;
     long long trace_pairs_ = 0, align_staged_pairs_ = 0;
-    uint8_t *h_rows_[2] = {nullptr, nullptr}, *d_rows_[2] = {nullptr, nullptr};
-    short *h_idx_[2] = {nullptr, nullptr}, *d_idx_[2] = {nullptr, nullptr};
+    uint8_t *h_rows_[kSlots] = {}, *d_rows_[kSlots] = {};
+    short *h_idx_[kSlots] = {}, *d_idx_[kSlots] = {};
+    hipEvent_t in_done_[kSlots] = {}, kernels_done_[kSlots] = {};   // align_host: H2D / kernels of the slot's chunk finished
 };
 
 }  // namespace valign

@@ -92,6 +92,7 @@ public:
                         engine_->describe(opt, aln_number));
         try {
             engine_->score_host(opt, aln_number, reads, refs, scores, threads);
+            log_line(0, "HIPKernel score done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
             log_line(3, e.what());
             throw;
@@ -106,6 +107,7 @@ public:
                         engine_->describe(opt, aln_number));
         try {
             engine_->align_host(opt, aln_number, reads, refs, alignments, threads);
+            log_line(0, "HIPKernel align done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
             log_line(3, e.what());
             throw;
