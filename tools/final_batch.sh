@@ -21,6 +21,13 @@ echo "align trace done"
 python tools/align_bench.py --iters 3 > $OUT/align_$TAG.log 2>&1 || exit 1
 { python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 ;
   python tools/geom_sweep.py --n 1048576 --geoms 8x20,16x10,16x12,32x8,64x12 --affine 1 ; } > $OUT/geom_$TAG.log 2>&1 || exit 1
+{ echo "# long reads: 2.5k x 5k (65536 pairs), 10k x 10k (32768 pairs = one GPU's share of BASELINE config 5), the same banded (512)";
+  python tools/geom_sweep.py --R 2500 --F 5000 --n 65536 --iters 2 --geoms 0x0;
+  python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0;
+  python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --band 512;
+  echo "# affine with four different scores (SW), NW affine";
+  python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 2;
+  python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 1 --opt 1; } 2>&1 | grep -v amdgpu.ids > $OUT/long_$TAG.log || exit 1
 echo "sweeps done"
 python tools/abi_bench.py --pairs 1048576 --align-pairs 262144 --threads 16 > $OUT/abi_$TAG.log 2>&1 || exit 1
 echo "abi done"
