@@ -77,10 +77,11 @@ constexpr Geometry make_geometry() {
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
 static const Geometry kGeometries[] = {
-    make_geometry<8, 4>(),   make_geometry<8, 8>(),   make_geometry<16, 4>(),  make_geometry<8, 12>(),
-    make_geometry<8, 16>(),  make_geometry<16, 8>(),  make_geometry<8, 20>(),  make_geometry<16, 10>(),
-    make_geometry<16, 12>(), make_geometry<16, 16>(), make_geometry<32, 8>(),  make_geometry<32, 12>(),
-    make_geometry<32, 16>(), make_geometry<64, 12>(), make_geometry<64, 16>(), make_geometry<64, 24>(),
+    make_geometry<8, 4>(),   make_geometry<8, 6>(),   make_geometry<8, 8>(),   make_geometry<16, 4>(),
+    make_geometry<8, 10>(),  make_geometry<8, 12>(),  make_geometry<8, 16>(),  make_geometry<16, 8>(),
+    make_geometry<8, 20>(),  make_geometry<16, 10>(), make_geometry<16, 12>(), make_geometry<16, 16>(),
+    make_geometry<32, 8>(),  make_geometry<32, 10>(), make_geometry<32, 12>(), make_geometry<32, 16>(),
+    make_geometry<64, 8>(),  make_geometry<64, 12>(), make_geometry<64, 16>(), make_geometry<64, 24>(),
     make_geometry<64, 32>(),
 };
 constexpr int kNumGeometries = sizeof(kGeometries) / sizeof(kGeometries[0]);
@@ -775,8 +776,12 @@ private:
                 }
             }
             if (best_waves == 0) continue;
-            // lane-steps per pair, weighted by instructions per step (per-row work + fixed part)
-            const double per_step = g.K * (sc_.affine ? 11.0 : 7.0) + 14.0;
+            // lane-steps per pair, weighted by instructions per step: per-row work + fixed part, measured
+            // on the score kernels (5.6 / 9.3 packed instructions per register, linear / affine), and a
+            // penalty for long register tiles, which lose occupancy (16x12: +14 %, 16x16: +35 %,
+            // 8x20: +60 % per step over the linear estimate; tools/shape_sweep.sh)
+            double per_step = g.K * (sc_.affine ? 9.3 : 5.6) + 7.0;
+            if (g.K > 10) per_step *= 1.0 + 0.06 * (g.K - 10);
             double cost = (double)(F + g.G - 1) * per_step * g.G / 2.0;
             if (best_waves < 8) cost *= 1.0 + 0.08 * (8 - best_waves);         // fewer than two waves per SIMD
             if (!best.geo || cost < best_cost) {

@@ -8,12 +8,12 @@
 #include "trace_kernels.hip.h"
 
 // Parts are balanced by rows per lane (compile time grows with K).
-#define VALIGN_GEOMETRIES_PART0(X) X(64, 32) X(8, 4)
-#define VALIGN_GEOMETRIES_PART1(X) X(64, 24) X(8, 12)
-#define VALIGN_GEOMETRIES_PART2(X) X(8, 20) X(8, 16)
-#define VALIGN_GEOMETRIES_PART3(X) X(16, 16) X(32, 16) X(16, 4)
-#define VALIGN_GEOMETRIES_PART4(X) X(64, 16) X(16, 12) X(8, 8)
-#define VALIGN_GEOMETRIES_PART5(X) X(32, 12) X(64, 12) X(16, 10)
+#define VALIGN_GEOMETRIES_PART0(X) X(64, 32) X(8, 4) X(8, 6)
+#define VALIGN_GEOMETRIES_PART1(X) X(64, 24) X(8, 12) X(16, 4)
+#define VALIGN_GEOMETRIES_PART2(X) X(8, 20) X(8, 16) X(8, 8)
+#define VALIGN_GEOMETRIES_PART3(X) X(16, 16) X(32, 16) X(8, 10)
+#define VALIGN_GEOMETRIES_PART4(X) X(64, 16) X(16, 12) X(32, 10)
+#define VALIGN_GEOMETRIES_PART5(X) X(32, 12) X(64, 12) X(16, 10) X(64, 8)
 #define VALIGN_GEOMETRIES_PART6(X) X(16, 8) X(32, 8)
 #define VALIGN_KERNEL_PARTS 7
 
