@@ -217,7 +217,7 @@ template <int G, int K, bool FIND_BAD>
 __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
                                            int prof_area, int refc_stride, int wave_lds, short match,
                                            short mismatch, WaveTables &w, bool bad_is_non_acgt = false,
-                                           unsigned block = blockIdx.x) {
+                                           unsigned block = blockIdx.x, short zero_score = 0) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -301,12 +301,13 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const short sc = valid ? (a == c + 1 ? match : mismatch) : (short)0;
+                const short sc = valid ? (a == c + 1 ? match : mismatch) : zero_score;
                 *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
             }
         }
+        const unsigned zero_pair = (unsigned)(unsigned short)zero_score * 0x00010001u;
         for (int idx = lane; idx < geo::kPairStride / 4; idx += kWave)
-            reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = 0u;
+            reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = zero_pair;
     }
     __syncthreads();
 #pragma unroll

@@ -51,7 +51,8 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][6];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][4];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy]
+    const void *fill[2][5];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+                                   //                               linear with the pointer tagged into the cell]
 };
 
 template <int G, int K>
@@ -70,9 +71,11 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSymF16>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>},
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>}}};
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -403,6 +406,15 @@ public:
         }
     }
 
+    // align_fill_tag_kernel keeps 4 * cell + tag in int16
+    bool tagged_range_ok(int alg) const {
+        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        const int worst = std::min({sc_.gap_read, sc_.gap_ref, sc_.mismatch, 0});
+        const long long lo = alg == kAlgSW ? worst : (long long)(R_ + F_ + 2) * worst;      // H(i,j) >= i gf + j gr
+        if (alg == kAlgSW && sc_.gap_ref >= 0) return false;
+        return 4 * hi + 4 <= 32000 && 4 * lo - 4 >= -32000 && std::abs(sc_.match) < 2000 && std::abs(sc_.mismatch) < 2000;
+    }
+
     // what score_alignments computes in for this mode at the engine's full shape
     const char *score_cell_format(int alg) const {
         if (alg > 1) return "none";
@@ -574,7 +586,10 @@ public:
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
         if (sse_policy_ && sc_.affine)
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
-        const void *fn = plan_.geo->fill[alg][sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0))];
+        // linear gaps, Default tie-breaks: the pointer rides in the low bits of the cell where 4x the cell
+        // range still fits int16 (and, for SW, gap_ref < 0); otherwise the equality-test kernels
+        const bool tagged = !sse_policy_ && !sc_.affine && !no_tag_ && tagged_range_ok(alg);
+        const void *fn = plan_.geo->fill[alg][tagged ? 4 : (sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -627,6 +642,7 @@ public:
             t.gap_ref = f.gap_ref;
             t.affine = sc_.affine ? 1 : 0;
             t.sse_policy = sse_policy_ ? 1 : 0;
+            t.tagged = tagged ? 1 : 0;
             t.open_read = f.open_read;
             t.ext_read = f.ext_read;
             t.open_ref = f.open_ref;
@@ -1144,6 +1160,7 @@ private:
     bool slot_ragged_[kSlots] = {};
     RaggedStats ragged_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
+    bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     std::string arch_;
     LaunchPlan plan_;

@@ -1,4 +1,4 @@
-// kernel_instances.hip.h -- which (G, K) geometries exist and in which translation unit their 20
+// kernel_instances.hip.h -- which (G, K) geometries exist and in which translation unit their 22
 // kernels are compiled.  The plugin is one shared object, but 340 kernel instances in one hipcc run
 // take minutes: hip_plugin.hip only declares them (extern template), kernel_part.hip is compiled
 // once per part (-DVALIGN_PART=n, in parallel, versalignlib_amd/build.py) and defines them.
@@ -42,4 +42,6 @@
     PREFIX __global__ void align_fill_affine_kernel<G, K, kAlgSW>(const FillArgs);                   \
     PREFIX __global__ void align_fill_affine_kernel<G, K, kAlgNW>(const FillArgs);                   \
     PREFIX __global__ void align_fill_sse_kernel<G, K, kAlgSW>(const FillArgs);                      \
-    PREFIX __global__ void align_fill_sse_kernel<G, K, kAlgNW>(const FillArgs);
+    PREFIX __global__ void align_fill_sse_kernel<G, K, kAlgNW>(const FillArgs);                      \
+    PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW>(const FillArgs);                      \
+    PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgNW>(const FillArgs);

@@ -59,7 +59,7 @@ __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
 template <int G, int K, int ALG, int NT>
 __device__ __forceinline__ void write_end_cells(const FillArgs &args, const WaveTables &w, const s16x2 (&rb)[NT],
                                                 const s16x2 (&fc)[NT], const int (&ir)[2], const int (&jr)[2],
-                                                int pad_rows, int lane, int grp, int l) {
+                                                int pad_rows, int lane, int grp, int l, int score_shift = 0) {
     // ---- end cell of each of the two pairs of this group ----
     const int base_lane = lane - l;
 #pragma unroll
@@ -90,7 +90,7 @@ __device__ __forceinline__ void write_end_cells(const FillArgs &args, const Wave
             const int p = 0xFFFF - (int)(kmax & 0xFFFF);
             const int win_lane = p / K;
             const int col_t = __shfl(bcol, base_lane + win_lane, kWave);
-            out.score = (short)(kmax >> 16);
+            out.score = (short)((kmax >> 16) >> score_shift);     // cells scaled by 4 in the tagged kernel
             out.read_pos = (short)(p - pad_rows);
             out.ref_pos = (short)(col_t - win_lane);
             if (out.score <= 0) {
@@ -174,7 +174,7 @@ align_fill_kernel(const FillArgs args) {
         } else {
             const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
             const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
-            sel[q] = s16x2{(short)(ta ? -1 : 0), (short)(tb ? -1 : 0)};
+            sel[q] = s16x2{(short)(ta ? 1 : 0), (short)(tb ? 1 : 0)};
             if (ta) nw_seed[0] = border;
             if (tb) nw_seed[1] = border;
         }
@@ -229,7 +229,9 @@ align_fill_kernel(const FillArgs args) {
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
                     rb[q] = pk_max(rb[q], hq);
                 } else {
-                    hs = as_pk((as_u32(sel[q]) & as_u32(hq)) | (~as_u32(sel[q]) & as_u32(hs)));
+                    unsigned v = as_u32(pk_mad_u(hq, sel[q], hs));      // sel is 1 for the one tracked row: picks its cell
+                    asm volatile("" : "+v"(v));                        // (pinned, see align_fill_tag_kernel)
+                    hs = as_pk(v);
                 }
             };
 #pragma unroll
@@ -287,6 +289,176 @@ align_fill_kernel(const FillArgs args) {
     for (; t < steps; ++t) step(std::true_type{}, t);
 
     write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
+}
+
+// Linear gaps, Default tie-breaks, with the back pointer carried INSIDE the cell value: every value
+// is kept as 4 * H + tag, tag 2 for the diagonal candidate (folded into the query profile: 4 * S + 2),
+// 1 for the candidate from above (folded into the gap constant), 0 for the one from the left.  One
+// packed maximum then resolves value AND origin with the reference's priority DIAG > UP > LEFT on
+// ties; `tag = h & 3` is the pointer, `h - tag` the clean cell for the next column.  Two 32-bit ANDs
+// replace the five packed instructions that derive the pointer from equality tests in
+// align_fill_kernel: 9 instead of 12 per register.  Needs 4x headroom in int16 and, for SW,
+// gap_ref < 0 (the engine falls back to align_fill_kernel otherwise).
+template <int G, int K, int ALG>
+__global__ void __launch_bounds__(256)
+align_fill_tag_kernel(const FillArgs args) {
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R;
+    const int pad_rows = geo::kRows - R;
+
+    WaveTables w;
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
+                                args.wave_lds, (short)(4 * args.match + 2), (short)(4 * args.mismatch + 2), w, false,
+                                blockIdx.x, (short)2))
+        return;
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+
+    const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;
+
+    // SW: magnitudes for the unsigned floor-at-zero subtract (4|g| from the left, 4|g| - 1 from above: the
+    // result carries tag 1); NW: signed addends 4g and 4g + 1
+    const s16x2 g_read = pk(ALG == kAlgSW ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read));
+    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
+    s16x2 four = pk(4), fifteen = pk(15);
+    unsigned tag_mask = 0x00030003u;
+    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask));
+
+    int ir[2], jr[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int p_local = 2 * grp + half;
+        p_local = p_local > w.last ? w.last : p_local;
+        ir[half] = w.first_bad[2 * p_local];
+        jr[half] = w.first_bad[2 * p_local + 1];
+    }
+
+    s16x2 Hl[K], tag[K], acc[K];
+    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    short nw_seed[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const int p = l * K + q;
+        short border = 0;
+        if (ALG == kAlgNW)                         // column 0 of the NW variant: i * gap_ref, i 1-based (scaled)
+            border = p < pad_rows ? (short)0 : (short)(4 * (p - pad_rows + 1) * args.gap_ref);
+        Hl[q] = pk(border);
+        tag[q] = pk(0);
+        acc[q] = pk(0);
+        if (ALG == kAlgSW) {
+            rb[q] = pk(0);
+            fc[q] = pk(0);
+        } else {
+            const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
+            const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
+            sel[q] = s16x2{(short)(ta ? 1 : 0), (short)(tb ? 1 : 0)};
+            if (ta) nw_seed[0] = border;
+            if (tb) nw_seed[1] = border;
+        }
+    }
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};
+        fc[0] = pk((short)l);
+    }
+    s16x2 h_last = Hl[K - 1];
+    s16x2 up0 = pk(0);
+    int j = -l;
+
+    const long long pp = w.pair0 / 2 + grp;
+    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+
+    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const s16x2 diag0 = up0;
+        if (G == 16) {
+            up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
+        } else {
+            up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        }
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            const s16x2 tt = pk((short)t);
+            // pass1(q): diagonal and left candidates of row q and their maximum -- only the previous column
+            // is needed, so it is computed one row ahead, between the links of the dependent chain
+            auto pass1 = [&](int q) __attribute__((always_inline)) -> s16x2 {
+                const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                               // tag 2
+                const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;   // tag 0
+                return pk_max(d, e);
+            };
+            s16x2 h = up0;
+            s16x2 hs = pk(0);
+            s16x2 h_prev = pk(0);
+            // arg-max bookkeeping of the previous row sits between the links of the dependent chain
+            auto finish_row = [&](int q, s16x2 hq) __attribute__((always_inline)) {
+                if (ALG == kAlgSW) {
+                    const s16x2 changed = (rb[q] - hq) >> fifteen;   // 0xFFFF where h beats the row best
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = pk_max(rb[q], hq);
+                } else {
+                    // sel[q] is 1 in the half whose tracked row this is (one row per pair), else 0: a packed
+                    // multiply-add picks that row's cell.  Pinned here: sunk to the end of the step pair (where
+                    // the optimiser wants it) every clean cell is rematerialised for it.
+                    unsigned v = as_u32(pk_mad_u(hq, sel[q], hs));
+                    asm volatile("" : "+v"(v));
+                    hs = as_pk(v);
+                }
+            };
+            s16x2 m_cur = pass1(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;              // tag 1
+                s16x2 m_next = pk(0);
+                if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] is overwritten
+                const s16x2 ht = pk_max(m_cur, f);
+                if (q > 0) finish_row(q - 1, h_prev);
+                tag[q] = as_pk(as_u32(ht) & tag_mask);
+                h = as_pk(as_u32(ht) & ~tag_mask);
+                Hl[q] = h;
+                h_prev = h;
+                m_cur = m_next;
+                // pin the order: left alone, the scheduler sinks the bookkeeping to the end of the step pair
+                // and rematerialises every clean cell for it
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            finish_row(K - 1, h_prev);
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = h;
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, tag[q]);
+        if ((t & 7) == 7) {
+            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
+#pragma unroll
+            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+        }
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t + 1 < steady_end; t += 2) {
+        step(std::false_type{}, t);
+        step(std::false_type{}, t + 1);
+    }
+    for (; t < steady_end; ++t) step(std::false_type{}, t);
+    for (; t < steps; ++t) step(std::true_type{}, t);
+
+    write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
 }
 
 // Affine-gap (Gotoh) fill -- an extension, the reference has no affine model.  Per cell two
@@ -352,7 +524,7 @@ align_fill_affine_kernel(const FillArgs args) {
         } else {
             const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
             const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
-            sel[q] = s16x2{(short)(ta ? -1 : 0), (short)(tb ? -1 : 0)};
+            sel[q] = s16x2{(short)(ta ? 1 : 0), (short)(tb ? 1 : 0)};
             if (ta) nw_seed[0] = border;
             if (tb) nw_seed[1] = border;
         }
@@ -408,7 +580,9 @@ align_fill_affine_kernel(const FillArgs args) {
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
                     rb[q] = pk_max(rb[q], h);
                 } else {
-                    hs = as_pk((as_u32(sel[q]) & as_u32(h)) | (~as_u32(sel[q]) & as_u32(hs)));
+                    unsigned v = as_u32(pk_mad_u(h, sel[q], hs));       // sel is 1 for the one tracked row: picks its cell
+                    asm volatile("" : "+v"(v));                        // (pinned, see align_fill_tag_kernel)
+                    hs = as_pk(v);
                 }
             }
             if (ALG == kAlgNW) {
@@ -614,6 +788,7 @@ struct TraceArgs {
     int alg;
     int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
     int sse_policy;           // 1: stored states are 0 START, 1 UP, 2 LEFT, 3 DIAG (SSE/AVX kernel rules)
+    int tagged;               // 1: codes are the tags of align_fill_tag_kernel (2 DIAG, 1 UP, 0 LEFT)
     short match, mismatch, gap_read, gap_ref;
     short open_read, ext_read, open_ref, ext_ref;
 };
@@ -707,6 +882,7 @@ traceback_kernel(const TraceArgs a) {
                 move = st == 3 ? 0 : st;
             } else if (!a.affine) {
                 move = code_at(wi, t);
+                if (a.tagged) move = 2 - move;
             } else if (state == 0) {
                 move = code_at(wi, t);                  // 0 DIAG, 1 enter F, 2 enter E
                 if (move != 0) {
