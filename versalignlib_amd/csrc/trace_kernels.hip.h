@@ -371,6 +371,19 @@ align_fill_tag_kernel(const FillArgs args) {
     const long long pp = w.pair0 / 2 + grp;
     unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
 
+    // LDS fetches run one step ahead of the arithmetic, as in score_kernel: raw profile dwords of this
+    // step in registers, rows of step t+1 and slab numbers of step t+2 requested now (every lane, every
+    // step; the code arrays are padded on both sides)
+    unsigned pa[K / 2], pb[K / 2];
+    unsigned ca_next, cb_next;
+    {
+        const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 2);
+        cb_next = *(lds_cu8 *)(code_addr + 3);
+    }
+
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
@@ -379,10 +392,13 @@ align_fill_tag_kernel(const FillArgs args) {
         } else {
             up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         }
+        s16x2 S[K];
+        merge_profile<K>(pa, pb, S);
+        lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 4);
+        cb_next = *(lds_cu8 *)(code_addr + 5);
         if (!MASKED || (unsigned)j < (unsigned)F) {
-            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
-            s16x2 S[K];
-            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             const s16x2 tt = pk((short)t);
             // pass1(q): diagonal and left candidates of row q and their maximum -- only the previous column
             // is needed, so it is computed one row ahead, between the links of the dependent chain
@@ -540,16 +556,32 @@ align_fill_affine_kernel(const FillArgs args) {
     const long long pp = w.pair0 / 2 + grp;
     unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * (2 * K);
 
+    // LDS fetches run one step ahead of the arithmetic, as in score_kernel: raw profile dwords of this
+    // step in registers, rows of step t+1 and slab numbers of step t+2 requested now (every lane, every
+    // step; the code arrays are padded on both sides)
+    unsigned pa[K / 2], pb[K / 2];
+    unsigned ca_next, cb_next;
+    {
+        const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 2);
+        cb_next = *(lds_cu8 *)(code_addr + 3);
+    }
+
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
         up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         const unsigned fv = from_prev_lane(as_u32(f_last));
         const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        s16x2 S[K];
+        merge_profile<K>(pa, pb, S);
+        lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 4);
+        cb_next = *(lds_cu8 *)(code_addr + 5);
         if (!MASKED || (unsigned)j < (unsigned)F) {
-            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
-            s16x2 S[K];
-            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             const s16x2 tt = pk((short)t);
             s16x2 d[K], m[K];
 #pragma unroll
