@@ -201,7 +201,7 @@ public:
         long long pairs = 0, pair_ofs = 0;
         size_t read_ofs = 0, ref_ofs = 0;
     };
-    struct RaggedStats {             // of the last score_host call
+    struct HostStats {             // of the last score_host call
         int launches = 0;
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
@@ -482,7 +482,7 @@ public:
         threads = std::min(threads, 64);
         const bool ragged = ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
         const bool shared_scratch = plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg);
-        ragged_stats_ = RaggedStats{};
+        host_stats_ = HostStats{};
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
             short *dst = scores + slot_begin_[s];
@@ -502,13 +502,13 @@ public:
             auto t1 = std::chrono::steady_clock::now();
             drain(slot);                            // the result of the chunk that used this slot
             auto t2 = std::chrono::steady_clock::now();
-            ragged_stats_.wait_ms += ms_between(t0, t1);
-            ragged_stats_.drain_ms += ms_between(t1, t2);
+            host_stats_.wait_ms += ms_between(t0, t1);
+            host_stats_.drain_ms += ms_between(t1, t2);
             // kernels that share a scratch (strip boundary rows) stay on one stream
             hipStream_t st = streams_[shared_scratch ? 0 : slot];
             if (ragged) {
                 const std::vector<LengthGroup> groups = gather_ragged(reads + begin, refs + begin, cnt, slot, threads);
-                ragged_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
+                host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
                 size_t read_bytes = 0, ref_bytes = 0;
                 for (const LengthGroup &g : groups) {
                     read_bytes = std::max(read_bytes, g.read_ofs + (size_t)g.pairs * g.R);
@@ -523,14 +523,14 @@ public:
                     while (end < groups.size() && groups[end].R == groups[first].R) widest = std::max(widest, groups[end++].F);
                     launch_score(class_plan(groups[first].R, widest), alg, groups[first].R, widest, 0, d_reads_[slot],
                                  d_refs_[slot], d_scores_[slot], st, groups.data() + first, (int)(end - first));
-                    ragged_stats_.launches += 1;
+                    host_stats_.launches += 1;
                     first = end;
                 }
-                for (const LengthGroup &g : groups) ragged_stats_.cells_swept += (double)g.pairs * g.R * g.F;
-                ragged_stats_.cells_padded += (double)cnt * R_ * F_;
+                for (const LengthGroup &g : groups) host_stats_.cells_swept += (double)g.pairs * g.R * g.F;
+                host_stats_.cells_padded += (double)cnt * R_ * F_;
             } else {
                 gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
-                ragged_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
+                host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
                 hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
                 hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
                 score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
@@ -547,8 +547,8 @@ public:
             hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
             auto t1 = std::chrono::steady_clock::now();
             drain(s);
-            ragged_stats_.wait_ms += ms_between(t0, t1);
-            ragged_stats_.drain_ms += ms_between(t1, std::chrono::steady_clock::now());
+            host_stats_.wait_ms += ms_between(t0, t1);
+            host_stats_.drain_ms += ms_between(t1, std::chrono::steady_clock::now());
         }
     }
 
@@ -677,12 +677,12 @@ public:
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
         hipStream_t kernels = streams_[0], copy_in = streams_[1], copy_out = streams_[2];
-        ragged_stats_ = RaggedStats{};
+        host_stats_ = HostStats{};
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
             const auto t0 = std::chrono::steady_clock::now();
             scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
-            ragged_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
+            host_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
             slot_pending_[s] = 0;
         };
         int slot = 0;
@@ -690,11 +690,11 @@ public:
             const long long cnt = std::min<long long>(chunk, n - begin);
             auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");   // its last chunk is back on the host
-            ragged_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
+            host_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(slot);
             t0 = std::chrono::steady_clock::now();
             gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
-            ragged_stats_.gather_ms += ms_between(t0, std::chrono::steady_clock::now());
+            host_stats_.gather_ms += ms_between(t0, std::chrono::steady_clock::now());
             hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, copy_in), "H2D reads");
             hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, copy_in), "H2D refs");
             hip_check(hipEventRecord(in_done_[slot], copy_in), "hipEventRecord");
@@ -712,7 +712,7 @@ public:
             const int s = (slot + k) % kSlots;
             const auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
-            ragged_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
+            host_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(s);
         }
     }
@@ -721,7 +721,7 @@ public:
     std::string host_phases() const {
         char buf[200];
         snprintf(buf, sizeof buf, "{\"host_gather_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
-                 ragged_stats_.gather_ms, ragged_stats_.wait_ms, ragged_stats_.drain_ms);
+                 host_stats_.gather_ms, host_stats_.wait_ms, host_stats_.drain_ms);
         return buf;
     }
 
@@ -737,10 +737,10 @@ public:
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
-                 plan_.long_mode ? 1 : 0, band_width_, ragged_, ragged_stats_.launches,
-                 ragged_stats_.cells_padded > 0 ? ragged_stats_.cells_swept / ragged_stats_.cells_padded : 1.0,
-                 score_cell_format(opt & 0xF), ragged_stats_.gather_ms, ragged_stats_.classify_ms, ragged_stats_.wait_ms,
-                 ragged_stats_.drain_ms);
+                 plan_.long_mode ? 1 : 0, band_width_, ragged_, host_stats_.launches,
+                 host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
+                 score_cell_format(opt & 0xF), host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+                 host_stats_.drain_ms);
         return buf;
     }
 
@@ -1046,7 +1046,7 @@ private:
                 mine[rc * NF + fc] += 1;
             }
         });
-        ragged_stats_.classify_ms += ms_between(t_begin, std::chrono::steady_clock::now());
+        host_stats_.classify_ms += ms_between(t_begin, std::chrono::steady_clock::now());
         // fold: a read class with too few pairs for a launch of its own joins the next read class
         // (bin by bin); inside a class, a reference bin smaller than a few blocks joins the next
         // wider one.  Both dimensions only ever grow, so the padded sweep still covers the pair.
@@ -1158,7 +1158,7 @@ private:
     std::vector<int> pos_[kSlots];
     std::unique_ptr<WorkerPool> pool_;
     bool slot_ragged_[kSlots] = {};
-    RaggedStats ragged_stats_;
+    HostStats host_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
