@@ -16,7 +16,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                    same affine extension) timed on the host cores on a bounded sample.
   linear_gap ..... the same batch in the reference's own linear-gap model (the bit-exact
                    path), and the reference's compiled CPU kernels timed beside it when
-                   oracle/_ref travelled with the repo.
+                   oracle/_ref travelled with the repo: Default (OpenMP, all threads), AVX2
+                   (one thread, as it runs on Linux) and AVX2 sharded over processes (all cores,
+                   as it was meant to run).
 """
 import argparse
 import json
@@ -182,7 +184,54 @@ def reference_cpu_kernels(reads, refs):
                          "kind": "reference", "sample": "%d pairs, SW linear-gap" % sample}
         except Exception as e:      # a reference kernel that cannot run here is reported, not fatal
             out[name] = {"error": str(e)[:200]}
+    try:
+        out["AVX_sharded"] = reference_avx_sharded(reads, refs, min(cores, 32))
+    except Exception as e:
+        out["AVX_sharded"] = {"error": str(e)[:200]}
     return out
+
+
+def reference_avx_sharded(reads, refs, procs, pairs_per_proc=32768):
+    """What the reference's AVX2 kernel was meant to do -- use every core (its OpenMP loop is compiled
+    out on Linux, AVXKernel.cpp:74-76): the sample is sharded over `procs` child processes, each
+    running the compiled libAVXKernel.so on one thread through the plugin protocol
+    (tools/ref_shard_worker.py: ctypes only, no torch, no GPU).  Children start together; the
+    slowest one's time counts."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from versalignlib_amd import build as b
+    plugin = os.path.join(ROOT, "oracle", "_ref", "libAVXKernel.so")
+    if not os.path.exists(plugin):
+        raise RuntimeError("oracle/_ref/libAVXKernel.so not built")
+    sample = min(int(reads.shape[0]), procs * pairs_per_proc)
+    per = sample // procs
+    sample = per * procs
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        np.save(os.path.join(d, "reads.npy"), reads[:sample].cpu().numpy())
+        np.save(os.path.join(d, "refs.npy"), refs[:sample].cpu().numpy())
+        worker = os.path.join(ROOT, "tools", "ref_shard_worker.py")
+        kids = [subprocess.Popen([sys.executable, worker, b.HOST_LIB, plugin, os.path.join(d, "reads.npy"),
+                                  os.path.join(d, "refs.npy"), str(i * per), str((i + 1) * per), d, str(i)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(procs)]
+        deadline = time.time() + 120
+        while sum(os.path.exists(os.path.join(d, "ready.%d" % i)) for i in range(procs)) < procs:
+            if time.time() > deadline or any(k.poll() not in (None, 0) for k in kids):
+                for k in kids:
+                    k.kill()
+                raise RuntimeError("reference shard workers did not come up")
+            time.sleep(0.01)
+        open(os.path.join(d, "go"), "w").close()
+        secs = []
+        for k in kids:
+            out, err = k.communicate(timeout=300)
+            if k.returncode != 0:
+                raise RuntimeError("shard worker failed: " + err[-200:])
+            secs.append(float(out.split()[0]))
+    slowest = max(secs)
+    return {"value": round(sample * R * F / slowest / 1e9, 3), "unit": "GCUPS", "processes": procs, "threads_each": 1,
+            "kind": "reference", "sample": "%d pairs over %d processes, SW linear-gap, slowest shard %.2f s"
+                                           % (sample, procs, slowest)}
 
 
 def main():
