@@ -51,8 +51,9 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][6];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][5];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
-                                   //                               linear with the pointer tagged into the cell]
+    const void *fill[2][6];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+                                   //                               linear with the pointer tagged into the cell, the same with
+                                   //                               one end-cell key per lane (SW)]
 };
 
 template <int G, int K>
@@ -72,10 +73,11 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW>},
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW>}}};
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false>, nullptr}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -589,7 +591,11 @@ public:
         // linear gaps, Default tie-breaks: the pointer rides in the low bits of the cell where 4x the cell
         // range still fits int16 (and, for SW, gap_ref < 0); otherwise the equality-test kernels
         const bool tagged = !sse_policy_ && !sc_.affine && !no_tag_ && tagged_range_ok(alg);
-        const void *fn = plan_.geo->fill[alg][tagged ? 4 : (sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
+        // SW: one (value, row) key per lane instead of a first-arg-max per row where value << 4 (5 bits of
+        // row for more than 16 rows per lane) still fits int16
+        const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
+        const bool lane_key = tagged && alg == kAlgSW && key_top <= 32000;
+        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),

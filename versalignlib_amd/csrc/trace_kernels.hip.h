@@ -56,7 +56,7 @@ __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
 
 // End cell of each of the two pairs of a lane group, from the per-row first arg-max registers
 // (reference rules: DefaultKernel.cpp:252-256 for SW, :307-315 / :381-387 for the NW variant).
-template <int G, int K, int ALG, int NT>
+template <int G, int K, int ALG, int KEYBITS = 0, int NT = 1>
 __device__ __forceinline__ void write_end_cells(const FillArgs &args, const WaveTables &w, const s16x2 (&rb)[NT],
                                                 const s16x2 (&fc)[NT], const int (&ir)[2], const int (&jr)[2],
                                                 int pad_rows, int lane, int grp, int l, int score_shift = 0) {
@@ -69,14 +69,22 @@ __device__ __forceinline__ void write_end_cells(const FillArgs &args, const Wave
         out.pad = 0;
         if constexpr (ALG == kAlgSW) {
             int bv = 0, bq = 0, bcol = 0;
+            if constexpr (KEYBITS > 0) {
+                // one (value, row) key per lane: value << KEYBITS | (2^KEYBITS - 1 - row), and its first column
+                const int key = half ? rb[0].y : rb[0].x;
+                bv = key >> KEYBITS;
+                bq = ((1 << KEYBITS) - 1) - (key & ((1 << KEYBITS) - 1));
+                bcol = (half ? fc[0].y : fc[0].x) & 0xFFFF;
+            } else {
 #pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const int v = half ? rb[q].y : rb[q].x;
-                const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
-                if (v > bv) {
-                    bv = v;
-                    bq = q;
-                    bcol = c;
+                for (int q = 0; q < K; ++q) {
+                    const int v = half ? rb[q].y : rb[q].x;
+                    const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
+                    if (v > bv) {
+                        bv = v;
+                        bq = q;
+                        bcol = c;
+                    }
                 }
             }
             // larger value first, then smaller row: rows are unique per lane so keys are too
@@ -299,9 +307,16 @@ align_fill_kernel(const FillArgs args) {
 // replace the five packed instructions that derive the pointer from equality tests in
 // align_fill_kernel: 9 instead of 12 per register.  Needs 4x headroom in int16 and, for SW,
 // gap_ref < 0 (the engine falls back to align_fill_kernel otherwise).
-template <int G, int K, int ALG>
+// LANEKEY (SW): the reference's end cell is the row-major first cell holding the maximum.  Instead of a
+// first-arg-max per row (4 packed instructions per register and step) each lane keeps ONE key
+// `value << b | (2^b - 1 - row)` -- larger value first, then the earlier row -- and the step at which
+// it last grew: a multiply-add and a maximum per register plus four instructions per step.  Needs
+// value << b to stay in int16 (the engine checks).
+template <int G, int K, int ALG, bool LANEKEY>
 __global__ void __launch_bounds__(256)
 align_fill_tag_kernel(const FillArgs args) {
+    static_assert(!LANEKEY || ALG == kAlgSW, "the lane key replaces the Smith-Waterman row arg-max");
+    constexpr int kKeyBits = K <= 16 ? 4 : 5;
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
@@ -324,9 +339,9 @@ align_fill_tag_kernel(const FillArgs args) {
     // result carries tag 1); NW: signed addends 4g and 4g + 1
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read));
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
-    s16x2 four = pk(4), fifteen = pk(15);
+    s16x2 four = pk(4), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 2)));     // cells are 4 * H already
     unsigned tag_mask = 0x00030003u;
-    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask));
+    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul));
 
     int ir[2], jr[2];
 #pragma unroll
@@ -338,7 +353,9 @@ align_fill_tag_kernel(const FillArgs args) {
     }
 
     s16x2 Hl[K], tag[K], acc[K];
-    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    constexpr int kTracked = (ALG == kAlgSW && !LANEKEY) ? K : 1;
+    s16x2 rb[kTracked], fc[kTracked], sel[ALG == kAlgNW ? K : 1];
+    s16x2 row_key[LANEKEY ? K : 1];              // 2^b - 1 - q: the earlier row wins among equal values
     short nw_seed[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < K; ++q) {
@@ -350,8 +367,15 @@ align_fill_tag_kernel(const FillArgs args) {
         tag[q] = pk(0);
         acc[q] = pk(0);
         if (ALG == kAlgSW) {
-            rb[q] = pk(0);
-            fc[q] = pk(0);
+            if (LANEKEY) {
+                row_key[q] = pk((short)((1 << kKeyBits) - 1 - q));
+                asm volatile("" : "+v"(row_key[q]));
+                rb[0] = pk(0);
+                fc[0] = pk(0);
+            } else {
+                rb[q] = pk(0);
+                fc[q] = pk(0);
+            }
         } else {
             const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
             const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
@@ -411,8 +435,11 @@ align_fill_tag_kernel(const FillArgs args) {
             s16x2 hs = pk(0);
             s16x2 h_prev = pk(0);
             // arg-max bookkeeping of the previous row sits between the links of the dependent chain
+            s16x2 step_key = pk(0);
             auto finish_row = [&](int q, s16x2 hq) __attribute__((always_inline)) {
-                if (ALG == kAlgSW) {
+                if (ALG == kAlgSW && LANEKEY) {
+                    step_key = pk_max(step_key, pk_mad_u(hq, key_mul, row_key[q]));
+                } else if (ALG == kAlgSW) {
                     const s16x2 changed = (rb[q] - hq) >> fifteen;   // 0xFFFF where h beats the row best
                     fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
                     rb[q] = pk_max(rb[q], hq);
@@ -443,6 +470,11 @@ align_fill_tag_kernel(const FillArgs args) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             finish_row(K - 1, h_prev);
+            if (ALG == kAlgSW && LANEKEY) {
+                const s16x2 changed = (rb[0] - step_key) >> fifteen;      // keys are >= 0: no wrap
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = pk_max(rb[0], step_key);
+            }
             if (ALG == kAlgNW) {
                 const s16x2 nb = pk_max(rb[0], hs);
                 const s16x2 changed = (rb[0] - nb) >> fifteen;
@@ -474,7 +506,8 @@ align_fill_tag_kernel(const FillArgs args) {
     for (; t < steady_end; ++t) step(std::false_type{}, t);
     for (; t < steps; ++t) step(std::true_type{}, t);
 
-    write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
+    if constexpr (LANEKEY) write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
+    else write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
 }
 
 // Affine-gap (Gotoh) fill -- an extension, the reference has no affine model.  Per cell two
