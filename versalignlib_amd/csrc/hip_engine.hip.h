@@ -51,9 +51,9 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][6];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][6];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+    const void *fill[2][7];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
                                    //                               linear with the pointer tagged into the cell, the same with
-                                   //                               one end-cell key per lane (SW)]
+                                   //                               one end-cell key per lane (SW), symmetric affine]
 };
 
 template <int G, int K>
@@ -72,12 +72,14 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSymF16>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true>},
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true>,
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW, true>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false>, nullptr}}};
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false>, nullptr,
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW, true>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -595,7 +597,8 @@ public:
         // row for more than 16 rows per lane) still fits int16
         const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
         const bool lane_key = tagged && alg == kAlgSW && key_top <= 32000;
-        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? 2 : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
+        const bool affine_sym = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
+        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? (affine_sym ? 6 : 2) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),

@@ -515,7 +515,9 @@ align_fill_tag_kernel(const FillArgs args) {
 // read; priority DIAG > F > E so that open == extend walks the linear path), and whether F / E were
 // extended (bit set) or opened from H (preferred on ties).  Pointer scratch per lane and 8-step
 // block: K dwords of H codes followed by K dwords of gap codes.
-template <int G, int K, int ALG>
+// SYM: open_read == open_ref and ext_read == ext_ref -- `H + open` is computed once per cell and serves E of
+// the next column and F of the next row (as in score_kernel's kGapAffineSym).
+template <int G, int K, int ALG, bool SYM>
 __global__ void __launch_bounds__(256)
 align_fill_affine_kernel(const FillArgs args) {
     using geo = Geo<G, K>;
@@ -556,6 +558,7 @@ align_fill_affine_kernel(const FillArgs args) {
     }
 
     s16x2 Hl[K], El[K], code_h[K], code_g[K], acc_h[K], acc_g[K];
+    s16x2 HOl[SYM ? K : 1];                    // H + open of the previous column
     s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
     short nw_seed[2] = {0, 0};
 #pragma unroll
@@ -565,6 +568,7 @@ align_fill_affine_kernel(const FillArgs args) {
         if (ALG == kAlgNW)                         // column 0: a gap of i bases in the ref direction
             border = p < pad_rows ? (short)0 : (short)(args.open_ref + (p - pad_rows) * args.ext_ref);
         Hl[q] = pk(border);
+        if (SYM) HOl[q] = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], o_read) : pk_add_sat(Hl[q], o_read);
         El[q] = border_f;
         code_h[q] = code_g[q] = acc_h[q] = acc_g[q] = pk(0);
         if (ALG == kAlgSW) {
@@ -620,7 +624,7 @@ align_fill_affine_kernel(const FillArgs args) {
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                const s16x2 e_open = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], o_read) : pk_add_sat(Hl[q], o_read);
+                const s16x2 e_open = SYM ? HOl[q] : ((ALG == kAlgSW) ? pk_sub_floor0(Hl[q], o_read) : pk_add_sat(Hl[q], o_read));
                 const s16x2 e_extd = (ALG == kAlgSW) ? pk_sub_floor0(El[q], e_read) : pk_add_sat(El[q], e_read);
                 const s16x2 e = pk_max(e_extd, e_open);
                 El[q] = e;
@@ -629,13 +633,18 @@ align_fill_affine_kernel(const FillArgs args) {
             }
             s16x2 h = up0, f = fup0;
             s16x2 hs = pk(0);
+            s16x2 ho = (ALG == kAlgSW) ? pk_sub_floor0(up0, o_ref) : pk_add_sat(up0, o_ref);     // SYM: H + open of the row above
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const s16x2 f_open = (ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref);
+                const s16x2 f_open = SYM ? ho : ((ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref));
                 const s16x2 f_extd = (ALG == kAlgSW) ? pk_sub_floor0(f, e_ref) : pk_add_sat(f, e_ref);
                 f = pk_max(f_extd, f_open);
                 h = pk_max(m[q], f);
                 Hl[q] = h;
+                if (SYM) {
+                    ho = (ALG == kAlgSW) ? pk_sub_floor0(h, o_ref) : pk_add_sat(h, o_ref);
+                    HOl[q] = ho;
+                }
                 const s16x2 nd = pk_min_u(h - d[q], one);
                 const s16x2 nf = pk_min_u(h - f, one);
                 code_h[q] = (s16x2)((u16x2)nd << (u16x2)nf);      // nd * (1 + nf): 0 DIAG, 1 from F, 2 from E
