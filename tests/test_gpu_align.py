@@ -253,3 +253,20 @@ def test_full_size_properties_config3():
     erows, eidx = cpu_ref.align(1, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3, *aff), threads=8, affine=True)
     assert np.array_equal(idx[0].cpu().numpy(), eidx) and np.array_equal(rows[0].cpu().numpy(), erows)
     eng.close()
+
+
+@pytest.mark.parametrize("R,F,n", [(2000, 1200, 24), (1500, 2500, 16), (700, 3000, 33)])
+def test_largest_register_geometries(R, F, n):
+    """Reads of up to 2048 rows still take the register sweep (64 lanes per pair, 12-32 rows per lane):
+    scores and alignments of both modes against the oracle."""
+    import torch
+    reads, refs = synth.make_pairs(n, R, F, seed=R, indel_rate=0.01, n_run_frac=0.1, short_frac=0.2)
+    eng = hipkernel.Engine(R, F)
+    assert eng.describe()["group_lanes"] == 64 and not eng.describe()["long_mode"]
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    for opt in (host.SW, host.NW):
+        rows, idx = eng.align_device(opt, d_reads, d_refs)
+        _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), cpu_ref.align(opt, reads, refs, threads=8), ("opt", opt))
+        assert np.array_equal(eng.score_device(opt, d_reads, d_refs).cpu().numpy(),
+                              cpu_ref.score(opt, reads, refs, threads=8))
+    eng.close()
