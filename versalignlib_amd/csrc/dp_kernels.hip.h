@@ -392,6 +392,11 @@ constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_
 // engine picks it when shape x scoring stays inside +-2048.
 constexpr int kGapAffineSymF16 = 4;
 constexpr int kGapAffineF16 = 5;      // half floats with four different open / extend scores: 9.5 instead of 11
+// Linear gaps with gap_read == gap_ref for the NW variant on half floats, cells kept as H + g: "left + g"
+// and "up + g" are then simply the neighbours' registers, the diagonal term is (H + g)_diag + (S - g)
+// with S - g folded into the query profile, and h + g = max3(...) + g -- perm, add, max3, add: 4 packed
+// instructions per register instead of 5 (the SW floor would need a fifth, so SW keeps kGapSym).
+constexpr int kGapSymF16 = 6;
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
 
@@ -403,6 +408,8 @@ score_kernel(const ScoreArgs args) {
     constexpr bool F16SYM = GAPS == kGapAffineSymF16;
     constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym || F16;
     constexpr bool SYM = GAPS == kGapSym;
+    constexpr bool LINF16 = GAPS == kGapSymF16;
+    static_assert(!LINF16 || ALG == kAlgNW, "the H + g form has no room for the Smith-Waterman floor");
     constexpr bool AFFSYM = GAPS == kGapAffineSym;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
@@ -427,10 +434,13 @@ score_kernel(const ScoreArgs args) {
 
     WaveTables w;
     // the query profile holds the substitution scores in the cell format of the recurrence
-    const short s_match = F16 ? __builtin_bit_cast(short, (_Float16)(int)args.match) : args.match;
-    const short s_mismatch = F16 ? __builtin_bit_cast(short, (_Float16)(int)args.mismatch) : args.mismatch;
+    // (kGapSymF16: S - g, also for the rows / bases that score 0)
+    const int fold = LINF16 ? -(int)args.gap_ref : 0;
+    const short s_match = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)((int)args.match + fold)) : args.match;
+    const short s_mismatch = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)((int)args.mismatch + fold)) : args.mismatch;
+    const short s_zero = LINF16 ? __builtin_bit_cast(short, (_Float16)fold) : (short)0;
     if (!wave_setup<G, K, false>(reads, refs, n_pairs, args.R, F_batch, args.prof_area, args.refc_stride,
-                                 args.wave_lds, s_match, s_mismatch, w, false, block))
+                                 args.wave_lds, s_match, s_mismatch, w, false, block, s_zero))
         return;
     const long long pair0 = w.pair0;
     // Smith-Waterman: columns after the last ACGT base of every reference in the wave (the NUL
@@ -467,13 +477,16 @@ score_kernel(const ScoreArgs args) {
     s16x2 Hl[K], El[K], HOl[K];
     const s16x2 ho_border = (ALG == kAlgSW) ? pk(0)               // border H (= 0) minus open
                                             : (F16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.open_ref)) : o_ref);
+    // kGapSymF16 keeps H + g: the zero border is g
+    const s16x2 lin_border = LINF16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.gap_ref)) : pk(0);
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-        Hl[q] = pk(0);
+        Hl[q] = lin_border;
         El[q] = border_f;
         HOl[q] = ho_border;
     }
-    s16x2 up0 = pk(0), h_last = pk(0), f_last = border_f, best = pk(0), row_best = pk(0);
+    s16x2 up0 = lin_border, h_last = lin_border, f_last = border_f, best = pk(0);
+    s16x2 row_best = LINF16 ? pk((short)0xFC00) : pk(0);        // kGapSymF16: maximum of H + g, starts at -inf
     int j = -l;                                                  // this lane's column at step t
 
     // LDS fetches run one step ahead of the arithmetic (every lane, every step: the code arrays are
@@ -502,7 +515,10 @@ score_kernel(const ScoreArgs args) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int TRACK = decltype(track_tag)::value;
         const s16x2 diag0 = up0;
-        if (G == 16) {             // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
+        if (LINF16) {              // the group leader's "row above" is the border, g in the H + g form
+            const unsigned above = from_prev_lane(as_u32(h_last));     // every lane takes part: a DPP read of a
+            up0 = as_pk(l == 0 ? as_u32(lin_border) : above);          // lane masked off by the select returns 0
+        } else if (G == 16) {      // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
         } else {
             up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
@@ -525,7 +541,24 @@ score_kernel(const ScoreArgs args) {
                 const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
                 fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             }
-            if (F16) {
+            if (LINF16) {
+                // hg = max3(hg_diag + (S - g), hg_left, hg_up) + g, everything in the H + g form
+                auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
+                const _Float16 gh = (_Float16)(int)args.gap_ref;
+                const f16x2 g_half = f16x2{gh, gh};
+                f16x2 hg = hf(up0);
+                f16x2 d_cur = hf(diag0) + hf(S[0]);
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    f16x2 d_next = d_cur;
+                    if (q + 1 < K) d_next = hf(Hl[q]) + hf(S[q + 1]);       // before Hl[q] is overwritten
+                    const f16x2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, hf(Hl[q])), hg);
+                    hg = m + g_half;
+                    Hl[q] = __builtin_bit_cast(s16x2, hg);
+                    d_cur = d_next;
+                }
+                h_last = __builtin_bit_cast(s16x2, hg);
+            } else if (F16) {
                 // Registers hold two half floats (bit patterns in the s16x2 containers).  pass1(q) -- diag + S
                 // and E of row q, which only need the previous column -- is written between the links of the
                 // dependent chain down the column (F, H, H - open), one row ahead.
@@ -635,7 +668,7 @@ score_kernel(const ScoreArgs args) {
                 f_last = f;
             }
             if (ALG == kAlgNW) {
-                if (F16) row_best = __builtin_bit_cast(s16x2, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, row_best),
+                if (F16 || LINF16) row_best = __builtin_bit_cast(s16x2, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, row_best),
                                                                                              __builtin_bit_cast(f16x2, h_last)));
                 else row_best = pk_max(row_best, h_last);
             }
@@ -663,7 +696,14 @@ score_kernel(const ScoreArgs args) {
 
     // ---- result ----
     s16x2 res;
-    if (F16) {
+    if (LINF16) {                 // back from H + g: max(0, last column, last row) = max(0, max(...) - g)
+        f16x2 b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk((short)0xFC00));
+#pragma unroll
+        for (int q = 0; q < K; ++q) b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, Hl[q]));
+        const _Float16 gh = (_Float16)(int)args.gap_ref;
+        b = __builtin_elementwise_maximum(b - f16x2{gh, gh}, f16x2{(_Float16)0, (_Float16)0});
+        res = s16x2{(short)(int)b.x, (short)(int)b.y};
+    } else if (F16) {
         f16x2 b = __builtin_bit_cast(f16x2, best);
         if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column)
             b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk(0));

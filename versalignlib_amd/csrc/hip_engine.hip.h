@@ -49,7 +49,7 @@ VALIGN_ALL_GEOMETRIES(VALIGN_DECLARE)
 struct Geometry {
     int G, K;
     WaveLds (*lds)(int R, int F);
-    const void *kernel[2][6];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
+    const void *kernel[2][7];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
     const void *fill[2][7];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
                                    //                               linear with the pointer tagged into the cell, the same with
@@ -64,13 +64,14 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSymF16>,
-                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineF16>},
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineF16>, nullptr},
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffineSymF16>,
-                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>}},
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapAffineF16>,
+                      (const void *)&score_kernel<G, K, kAlgNW, kGapSymF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false>,
@@ -347,6 +348,7 @@ public:
             if (!no_f16_ && half_float_exact(alg, R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
+            if (gaps == kGapSym && alg == kAlgNW && !no_f16_ && half_float_exact(alg, R, F)) gaps = kGapSymF16;
         }
         const void *fn = plan.geo->kernel[alg][gaps];
         const int block_lds = plan.lds.total * plan.waves_per_block;
@@ -424,6 +426,9 @@ public:
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
         if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_)) return "f16";
+        if (!plan_.long_mode && !sc_.affine && alg == kAlgNW && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ &&
+            half_float_exact(alg, R_, F_))
+            return "f16";
         return "int16";
     }
 
