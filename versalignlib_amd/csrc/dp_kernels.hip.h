@@ -395,7 +395,10 @@ constexpr int kGapAffineF16 = 5;      // half floats with four different open / 
 // Linear gaps with gap_read == gap_ref for the NW variant on half floats, cells kept as H + g: "left + g"
 // and "up + g" are then simply the neighbours' registers, the diagonal term is (H + g)_diag + (S - g)
 // with S - g folded into the query profile, and h + g = max3(...) + g -- perm, add, max3, add: 4 packed
-// instructions per register instead of 5 (the SW floor would need a fifth, so SW keeps kGapSym).
+// instructions per register instead of 5.  Smith-Waterman needs the zero floor as well: there every value
+// is additionally scaled by 2^-10 (exact for integers below 1024), which turns the floor into the
+// hardware clamp of v_pk_add_f16 -- max(h + g, 0) is ONE instruction, and a register pair (h, max(h + g, 0))
+// per cell gives h = max3(diag + S, left', up'), left' / up' being the clamped registers: also 4.
 constexpr int kGapSymF16 = 6;
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
@@ -409,7 +412,6 @@ score_kernel(const ScoreArgs args) {
     constexpr bool AFFINE = GAPS == kGapAffine || GAPS == kGapAffineSym || F16;
     constexpr bool SYM = GAPS == kGapSym;
     constexpr bool LINF16 = GAPS == kGapSymF16;
-    static_assert(!LINF16 || ALG == kAlgNW, "the H + g form has no room for the Smith-Waterman floor");
     constexpr bool AFFSYM = GAPS == kGapAffineSym;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
@@ -435,10 +437,13 @@ score_kernel(const ScoreArgs args) {
     WaveTables w;
     // the query profile holds the substitution scores in the cell format of the recurrence
     // (kGapSymF16: S - g, also for the rows / bases that score 0)
-    const int fold = LINF16 ? -(int)args.gap_ref : 0;
-    const short s_match = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)((int)args.match + fold)) : args.match;
-    const short s_mismatch = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)((int)args.mismatch + fold)) : args.mismatch;
-    const short s_zero = LINF16 ? __builtin_bit_cast(short, (_Float16)fold) : (short)0;
+    // (kGapSymF16: NW S - g, also for the rows / bases that score 0; SW S * 2^-10)
+    constexpr bool LINF16_SW = LINF16 && ALG == kAlgSW, LINF16_NW = LINF16 && ALG == kAlgNW;
+    const int fold = LINF16_NW ? -(int)args.gap_ref : 0;
+    const float unit = LINF16_SW ? 1.0f / 1024.0f : 1.0f;
+    const short s_match = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)(((int)args.match + fold) * unit)) : args.match;
+    const short s_mismatch = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)(((int)args.mismatch + fold) * unit)) : args.mismatch;
+    const short s_zero = LINF16_NW ? __builtin_bit_cast(short, (_Float16)fold) : (short)0;
     if (!wave_setup<G, K, false>(reads, refs, n_pairs, args.R, F_batch, args.prof_area, args.refc_stride,
                                  args.wave_lds, s_match, s_mismatch, w, false, block, s_zero))
         return;
@@ -478,7 +483,7 @@ score_kernel(const ScoreArgs args) {
     const s16x2 ho_border = (ALG == kAlgSW) ? pk(0)               // border H (= 0) minus open
                                             : (F16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.open_ref)) : o_ref);
     // kGapSymF16 keeps H + g: the zero border is g
-    const s16x2 lin_border = LINF16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.gap_ref)) : pk(0);
+    const s16x2 lin_border = LINF16_NW ? pk(__builtin_bit_cast(short, (_Float16)(int)args.gap_ref)) : pk(0);
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         Hl[q] = lin_border;
@@ -486,7 +491,7 @@ score_kernel(const ScoreArgs args) {
         HOl[q] = ho_border;
     }
     s16x2 up0 = lin_border, h_last = lin_border, f_last = border_f, best = pk(0);
-    s16x2 row_best = LINF16 ? pk((short)0xFC00) : pk(0);        // kGapSymF16: maximum of H + g, starts at -inf
+    s16x2 row_best = LINF16_NW ? pk((short)0xFC00) : pk(0);     // kGapSymF16 (NW): maximum of H + g, starts at -inf
     int j = -l;                                                  // this lane's column at step t
 
     // LDS fetches run one step ahead of the arithmetic (every lane, every step: the code arrays are
@@ -515,7 +520,7 @@ score_kernel(const ScoreArgs args) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int TRACK = decltype(track_tag)::value;
         const s16x2 diag0 = up0;
-        if (LINF16) {              // the group leader's "row above" is the border, g in the H + g form
+        if (LINF16_NW) {           // the group leader's "row above" is the border, g in the H + g form
             const unsigned above = from_prev_lane(as_u32(h_last));     // every lane takes part: a DPP read of a
             up0 = as_pk(l == 0 ? as_u32(lin_border) : above);          // lane masked off by the select returns 0
         } else if (G == 16) {      // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
@@ -528,6 +533,8 @@ score_kernel(const ScoreArgs args) {
             const unsigned fv = from_prev_lane(as_u32(f_last));
             fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
         }
+        s16x2 gup0 = pk(0);        // kGapSymF16 (SW): max(h + g, 0) of the row above
+        if (LINF16_SW) gup0 = as_pk(from_prev_lane(as_u32(f_last)) & lmask);
         s16x2 S[K];
         if (PIPE) {
             merge_profile<K>(pa, pb, S);                                     // step t's scores
@@ -541,7 +548,34 @@ score_kernel(const ScoreArgs args) {
                 const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
                 fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
             }
-            if (LINF16) {
+            if (LINF16_SW) {
+                // h = max3(diag + S, left', up') with x' = max(x + g, 0) kept beside x (El[] holds the x');
+                // everything times 2^-10, so the floor is the clamp of the packed add
+                auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
+                auto bits = [](f16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(s16x2, v); };
+                const _Float16 gs = (_Float16)((int)args.gap_ref * (1.0f / 1024.0f));
+                const f16x2 g_unit = f16x2{gs, gs}, zero2 = f16x2{(_Float16)0, (_Float16)0}, one2 = f16x2{(_Float16)1, (_Float16)1};
+                f16x2 up_c = hf(gup0);
+                f16x2 h = zero2;
+                f16x2 d_cur = hf(diag0) + hf(S[0]), d_prev = zero2;
+                f16x2 bestf = hf(best);
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    f16x2 d_next = d_cur;
+                    if (q + 1 < K) d_next = hf(Hl[q]) + hf(S[q + 1]);       // before Hl[q] is overwritten
+                    h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, hf(El[q])), up_c);
+                    Hl[q] = bits(h);
+                    up_c = __builtin_elementwise_min(__builtin_elementwise_max(h + g_unit, zero2), one2);   // v_pk_add_f16 clamp
+                    El[q] = bits(up_c);
+                    if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
+                    else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
+                    d_prev = d_cur;
+                    d_cur = d_next;
+                }
+                best = bits(bestf);
+                h_last = bits(h);
+                f_last = bits(up_c);
+            } else if (LINF16) {
                 // hg = max3(hg_diag + (S - g), hg_left, hg_up) + g, everything in the H + g form
                 auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
                 const _Float16 gh = (_Float16)(int)args.gap_ref;
@@ -696,7 +730,10 @@ score_kernel(const ScoreArgs args) {
 
     // ---- result ----
     s16x2 res;
-    if (LINF16) {                 // back from H + g: max(0, last column, last row) = max(0, max(...) - g)
+    if (LINF16_SW) {
+        const f16x2 b = __builtin_bit_cast(f16x2, best);
+        res = s16x2{(short)(int)((float)b.x * 1024.0f), (short)(int)((float)b.y * 1024.0f)};
+    } else if (LINF16) {          // back from H + g: max(0, last column, last row) = max(0, max(...) - g)
         f16x2 b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk((short)0xFC00));
 #pragma unroll
         for (int q = 0; q < K; ++q) b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, Hl[q]));

@@ -64,7 +64,8 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffine>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSym>,
                       (const void *)&score_kernel<G, K, kAlgSW, kGapAffineSymF16>,
-                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineF16>, nullptr},
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapAffineF16>,
+                      (const void *)&score_kernel<G, K, kAlgSW, kGapSymF16>},
                      {(const void *)&score_kernel<G, K, kAlgNW, kGapLinear>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSym>,
                       (const void *)&score_kernel<G, K, kAlgNW, kGapAffine>,
@@ -348,7 +349,8 @@ public:
             if (!no_f16_ && half_float_exact(alg, R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
-            if (gaps == kGapSym && alg == kAlgNW && !no_f16_ && half_float_exact(alg, R, F)) gaps = kGapSymF16;
+            if (gaps == kGapSym && !no_f16_ && (alg == kAlgNW ? half_float_exact(alg, R, F) : half_float_unit_exact(R, F)))
+                gaps = kGapSymF16;
         }
         const void *fn = plan.geo->kernel[alg][gaps];
         const int block_lds = plan.lds.total * plan.waves_per_block;
@@ -426,8 +428,8 @@ public:
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
         if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_)) return "f16";
-        if (!plan_.long_mode && !sc_.affine && alg == kAlgNW && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ &&
-            half_float_exact(alg, R_, F_))
+        if (!plan_.long_mode && !sc_.affine && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ &&
+            (alg == kAlgNW ? half_float_exact(alg, R_, F_) : half_float_unit_exact(R_, F_)))
             return "f16";
         return "int16";
     }
@@ -441,6 +443,14 @@ public:
                                           std::abs(sc_.ext_read), std::abs(sc_.open_ref), std::abs(sc_.ext_ref)});
         const long long bottom = alg == kAlgSW ? 0 : (long long)(std::min(R, F) + 2) * slack;
         return top + 2 * slack <= 2048 && bottom + 2 * slack <= 2048 && slack <= 1024;
+    }
+
+    // kGapSymF16 for Smith-Waterman scales every value by 2^-10 and floors with the [0, 1] clamp of the
+    // packed add: cells must stay below 1024, scores be integers of magnitude < 1024
+    bool half_float_unit_exact(int R, int F) const {
+        const long long top = (long long)std::min(R, F) * std::max({sc_.match, sc_.mismatch, 0});
+        const long long slack = std::max({std::abs(sc_.match), std::abs(sc_.mismatch), std::abs(sc_.gap_read), std::abs(sc_.gap_ref)});
+        return top + 2 * slack < 1024 && slack < 512;
     }
 
     // int16 DP cells: the reference wraps silently.  Scores switch to int32 cells on the strip path

@@ -36,6 +36,7 @@
     PREFIX __global__ void score_kernel<G, K, kAlgNW, kGapAffineSymF16>(const ScoreArgs);            \
     PREFIX __global__ void score_kernel<G, K, kAlgNW, kGapAffineF16>(const ScoreArgs);               \
     PREFIX __global__ void score_kernel<G, K, kAlgNW, kGapSymF16>(const ScoreArgs);                  \
+    PREFIX __global__ void score_kernel<G, K, kAlgSW, kGapSymF16>(const ScoreArgs);                  \
     PREFIX __global__ void align_fill_kernel<G, K, kAlgSW, false>(const FillArgs);                   \
     PREFIX __global__ void align_fill_kernel<G, K, kAlgSW, true>(const FillArgs);                    \
     PREFIX __global__ void align_fill_kernel<G, K, kAlgNW, false>(const FillArgs);                   \
