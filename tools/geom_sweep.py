@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--affine", type=int, default=0, help="1: open -5 / extend -1 both ways; 2: four different scores")
     ap.add_argument("--opt", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0, help="score_width: 0 auto, 16, 32 (int32 cells, strip path)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
@@ -44,6 +45,8 @@ def main():
             continue
         if a.band:
             eng.set_band_width(a.band)
+        if a.width:
+            eng.set_score_width(a.width)
         out = eng.score_device(a.opt, reads, refs)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

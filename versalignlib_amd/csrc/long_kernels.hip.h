@@ -162,8 +162,11 @@ score_long_kernel(const LongArgs args) {
         unsigned *brow_cur = args.brow + (long long)(s & 1) * args.pp_total * args.row_dwords;
 
         cell_t Hl[K];
+        int Gl[(SYM && WIDE && ALG == kAlgSW) ? K : 1];       // int32 SW: max(h - g, 0) of the previous column
 #pragma unroll
         for (int q = 0; q < K; ++q) Hl[q] = ops::bc(0);
+#pragma unroll
+        for (int q = 0; q < ((SYM && WIDE && ALG == kAlgSW) ? K : 1); ++q) Gl[q] = 0;
         cell_t up0 = ops::bc(0), h_last = ops::bc(0);
         if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
             up0 = ops::from_bits(__builtin_nontemporal_load(brow_prev + brow_slot * args.row_dwords + (c_lo - 1)));
@@ -207,7 +210,34 @@ score_long_kernel(const LongArgs args) {
                 // column-independent work of row q+1 sits between the links of the dependent chain of
                 // row q (see score_kernel)
                 cell_t h = up0;
-                if (SYM) {
+                if constexpr (SYM && WIDE && ALG == kAlgSW) {
+                    // int32 cells have a three-operand maximum and a saturating subtract: each cell keeps
+                    // (h, max(h - g, 0)) and h = max3(diag + S, left', up') on the floored registers is
+                    // non-negative by construction -- add, max3, sub-clamp per cell instead of add, max, sub,
+                    // max, max (the packed int16 form has no max3).  The maximum takes two rows per max3.
+                    const unsigned gmag = (unsigned)g_ref;
+                    int up_c = (int)__builtin_elementwise_sub_sat((unsigned)up0, gmag);
+                    int d_cur = diag0 + S[0], d_prev = 0;
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        int d_next = 0;
+                        if (q + 1 < K) d_next = Hl[q] + S[q + 1];          // before Hl[q] is overwritten
+                        int m = d_cur > Gl[q] ? d_cur : Gl[q];
+                        m = m > up_c ? m : up_c;
+                        h = m;
+                        Hl[q] = m;
+                        up_c = (int)__builtin_elementwise_sub_sat((unsigned)m, gmag);
+                        Gl[q] = up_c;
+                        if (q & 1) {
+                            int b2 = best > d_prev ? best : d_prev;
+                            best = b2 > d_cur ? b2 : d_cur;
+                        } else if (q == K - 1) {
+                            best = best > d_cur ? best : d_cur;
+                        }
+                        d_prev = d_cur;
+                        d_cur = d_next;
+                    }
+                } else if (SYM) {
                     cell_t d_cur = diag0 + S[0];
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
