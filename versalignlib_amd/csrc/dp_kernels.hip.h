@@ -27,10 +27,14 @@
 //     model (profile_conflicts) finds conflict-free.  Inputs are raw ASCII as delivered
 //     by the ABI (1 byte per base): refs via 16-byte coalesced loads, reads as coalesced
 //     byte loads.
-//   * Recurrence variants (GAPS): two linear gap scores (7 packed instructions per
-//     register = per two cells), one shared gap score (6), affine (11), affine with the
-//     same open/extend for both directions (10).  The SW maximum is tracked on diag+S,
-//     off the dependency chain.
+//   * Recurrence variants (GAPS), packed instructions per register (= per two cells) incl. the
+//     profile merge: two linear gap scores 6 + maximum tracking, one shared gap score 5 +
+//     tracking, affine 10, affine with the same open/extend for both directions 9.  Where every
+//     cell provably stays a small integer the same recurrences run on packed HALF FLOATS, which
+//     gfx950 gives a three-operand maximum (v_pk_maximum3_f16) and a free [0, 1] clamp on the
+//     add: shared-gap linear 4 (NW keeps H + g, SW keeps (h, max(h + g, 0)) scaled by 2^-10),
+//     symmetric affine 8, affine 9 -- results identical to the int16 forms, which remain the
+//     fallback.  The SW maximum is tracked on diag+S, off the dependency chain.
 //   * Pipeline fill/drain steps EXEC-mask lanes outside columns [0, F) (finished lanes keep
 //     the values of the last column, needed by the NW-variant result); the steady phase
 //     runs unmasked.
