@@ -219,3 +219,27 @@ def test_ragged_batches_skip_trailing_padding_exactly():
         rows, idx = hip.compute_alignments(0, reads, refs, normalise=False)
         erows, eidx = cpu_ref.align(0, reads, refs, threads=8)
         assert np.array_equal(idx, eidx) and np.array_equal(rows, erows)
+
+
+@pytest.mark.parametrize("aff", [None, (-5, -1, -5, -1), (-5, -1, -4, -2)])
+def test_half_float_and_int16_forms_agree(monkeypatch, aff):
+    """Every recurrence has an int16 form (the fallback beyond the half-float range) and, where cells stay
+    small integers, a half-float form: same scores from both, on the same batch, and both equal the oracle."""
+    import torch
+    R, F, n = 150, 500, 3000
+    reads, refs = _data(R, F, n, 91)
+    kw = {} if aff is None else dict(open_read=aff[0], ext_read=aff[1], open_ref=aff[2], ext_ref=aff[3])
+    osc = cpu_ref.Scoring.make(2, -1, -3, -3, **kw)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    fast = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **kw))
+    monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+    plain = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **kw))
+    monkeypatch.delenv("VALIGN_HIP_NO_F16")
+    for opt in (host.SW, host.NW):
+        assert fast.describe(opt)["score_cells"] == "f16" and plain.describe(opt)["score_cells"] == "int16"
+        a = fast.score_device(opt, d_reads, d_refs).cpu().numpy()
+        b = plain.score_device(opt, d_reads, d_refs).cpu().numpy()
+        exp = cpu_ref.score(opt, reads, refs, osc, threads=8, affine=aff is not None)
+        assert np.array_equal(a, exp) and np.array_equal(b, exp), opt
+    fast.close()
+    plain.close()
