@@ -272,21 +272,27 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             unsigned char *dst = refc + g * refc_stride + 2 * col;
             dst[0] = dst[1] = (unsigned char)geo::kZeroSlab;
         }
-        for (int idx = lane; idx < geo::kGroups * F; idx += kWave) {
-            const int g = idx / F, j = idx - g * F;
+        // one lane group after the other (no division by the runtime F), both slab numbers in one store
+#pragma unroll
+        for (int g = 0; g < geo::kGroups; ++g) {
             int pa = 2 * g, pb = 2 * g + 1;
             pa = pa > last ? last : pa;
             pb = pb > last ? last : pb;
-            const int ca = base_class(prof[ref_skew + pa * F + j]);
-            const int cb = base_class(prof[ref_skew + pb * F + j]);
-            unsigned char *dst = refc + g * refc_stride + 2 * (j + kCodePad);
-            dst[0] = (unsigned char)((ca >= 1 && ca <= 4) ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab);
-            dst[1] = (unsigned char)((cb >= 1 && cb <= 4) ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab);
-            if ((ca >= 1 && ca <= 4) || (cb >= 1 && cb <= 4)) cols_used = j + 1 > cols_used ? j + 1 : cols_used;
-            if (FIND_BAD) {
-                // "invalid" for the NW end cell: class 0 (Default kernel) or anything but ACGT (SSE kernel)
-                if (ca == 0 || (bad_is_non_acgt && ca == 5)) atomicMin(&first_bad[2 * (2 * g) + 1], j);
-                if (cb == 0 || (bad_is_non_acgt && cb == 5)) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
+            const unsigned char *raw_a = prof + ref_skew + pa * F, *raw_b = prof + ref_skew + pb * F;
+            unsigned char *codes_g = refc + g * refc_stride + 2 * kCodePad;
+            for (int j = lane; j < F; j += kWave) {
+                const int ca = base_class(raw_a[j]);
+                const int cb = base_class(raw_b[j]);
+                const bool va = ca >= 1 && ca <= 4, vb = cb >= 1 && cb <= 4;
+                const unsigned sa = va ? (ca - 1) * geo::kPairs + 2 * g : geo::kZeroSlab;
+                const unsigned sb = vb ? (cb - 1) * geo::kPairs + 2 * g + 1 : geo::kZeroSlab;
+                *reinterpret_cast<unsigned short *>(codes_g + 2 * j) = (unsigned short)(sa | (sb << 8));
+                if (va || vb) cols_used = j + 1 > cols_used ? j + 1 : cols_used;
+                if (FIND_BAD) {
+                    // "invalid" for the NW end cell: class 0 (Default kernel) or anything but ACGT (SSE kernel)
+                    if (ca == 0 || (bad_is_non_acgt && ca == 5)) atomicMin(&first_bad[2 * (2 * g) + 1], j);
+                    if (cb == 0 || (bad_is_non_acgt && cb == 5)) atomicMin(&first_bad[2 * (2 * g + 1) + 1], j);
+                }
             }
         }
     }
