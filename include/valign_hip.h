@@ -27,6 +27,10 @@
  *                                                         (trailing non-ACGT padding is not swept,
  *                                                         identical scores): 0 never, 1 when a sample
  *                                                         of the call is ragged enough (default), 2 always
+ *       host_malloc_tuning .............................. 1: mallopt(M_TRIM_THRESHOLD / M_TOP_PAD) at spawn so that
+ *                                                         the 2n result blocks of large compute_alignments
+ *                                                         calls are recycled instead of trimmed and re-faulted
+ *                                                         (changes the host's allocator; default 0)
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *

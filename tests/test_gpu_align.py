@@ -270,3 +270,12 @@ def test_largest_register_geometries(R, F, n):
         assert np.array_equal(eng.score_device(opt, d_reads, d_refs).cpu().numpy(),
                               cpu_ref.score(opt, reads, refs, threads=8))
     eng.close()
+
+
+def test_host_malloc_tuning_key_changes_nothing_but_the_allocator():
+    R, F, n = 64, 128, 5000
+    reads, refs = _data(R, F, n, 93)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, host_malloc_tuning=1) as hip:
+        for _ in range(2):                                    # second call recycles the first call's blocks
+            got = hip.compute_alignments(host.SW, reads, refs, normalise=False)
+        _assert_same(got, cpu_ref.align(host.SW, reads, refs, threads=8), "tuned")

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1 << 18)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--align-pairs", type=int, default=1 << 16)
+    ap.add_argument("--malloc-tuning", type=int, default=0, help="plugin key host_malloc_tuning")
     ap.add_argument("--ragged", action="store_true",
                     help="mixed-length, NUL-padded sequences; times score_alignments with length-sorted "
                          "batching on and off (GCUPS counted on the padded shape, as the reference does)")
@@ -39,7 +40,7 @@ def main():
                                   "pairs": a.pairs, "threads": a.threads, "seconds": round(best, 4),
                                   "padded_gcups_pcie_inclusive": round(synth.gcups(a.pairs, R, F, best), 1)}))
         return
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=a.threads) as k:
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=a.threads, host_malloc_tuning=a.malloc_tuning) as k:
         k.score_alignments(0, reads[:blk], refs[:blk])
         for rep in range(3):
             _, sec = k.score_alignments(0, reads, refs, scattered=True)
