@@ -51,9 +51,10 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][7];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][7];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+    const void *fill[2][9];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
                                    //                               linear with the pointer tagged into the cell, the same with
-                                   //                               one end-cell key per lane (SW), symmetric affine]
+                                   //                               one end-cell key per lane (SW), symmetric affine,
+                                   //                               affine / symmetric affine with tagged cells]
 };
 
 template <int G, int K>
@@ -77,11 +78,15 @@ constexpr Geometry make_geometry() {
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true>,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW, true>},
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgSW, true>,
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, false>,
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, true>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false>, nullptr,
-                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW, true>}}};
+                      (const void *)&align_fill_affine_kernel<G, K, kAlgNW, true>,
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, false>,
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, true>}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -414,6 +419,21 @@ public:
         }
     }
 
+    // align_fill_affine_tag_kernel keeps 8 * cell + tag in int16; SW needs open scores < 0 (the tag rides on the
+    // open constant) and, for the lane key, value << 4 (5) in range
+    bool affine_tagged_range_ok(int alg) const {
+        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        const int worst = std::min({sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, sc_.mismatch, 0});
+        // NW: every cell is at least the path "one gap up, one gap left"; E / F sit one open below H
+        const long long lo = alg == kAlgSW ? worst
+                                           : 2ll * (std::min(sc_.open_read, 0) + std::min(sc_.open_ref, 0)) +
+                                                 (long long)(R_ + F_ + 2) * std::min({sc_.ext_read, sc_.ext_ref, 0}) + worst;
+        if (alg == kAlgSW && (sc_.open_read >= 0 || sc_.open_ref >= 0)) return false;
+        const int key_bits = plan_.geo->K <= 16 ? 4 : 5;
+        if (alg == kAlgSW && ((hi + 1) << key_bits) > 32000) return false;
+        return 8 * hi + 8 <= 32000 && 8 * lo - 8 >= -28000 && std::abs(sc_.match) < 1000 && std::abs(sc_.mismatch) < 1000;
+    }
+
     // align_fill_tag_kernel keeps 4 * cell + tag in int16
     bool tagged_range_ok(int alg) const {
         const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
@@ -589,9 +609,13 @@ public:
             throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
-        const int blocks8 = (F_ + G - 1 + 7) / 8;
+        // affine gaps with the traceback information tagged into the cells (4-bit codes, 4-step blocks)
+        const bool affine_tagged = sc_.affine && !sse_policy_ && !no_tag_ && affine_tagged_range_ok(alg);
+        int blocks8 = affine_tagged ? (F_ + G - 1 + 3) / 4 : (F_ + G - 1 + 7) / 8;            // blocks of steps per lane
+        const int burst = hold_blocks(K);                 // the tagged kernels store this many blocks at a time
+        blocks8 = (blocks8 + burst - 1) / burst * burst;
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4 * (sc_.affine ? 2 : 1);
+        const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4 * ((sc_.affine && !affine_tagged) ? 2 : 1);
         // Pointer scratch: as much of the batch per launch as memory allows (a 1 M-pair launch keeps
         // the latency-bound traceback kernel at full occupancy), capped at 24 GiB and half the free HBM.
         size_t free_b = 0, total_b = 0;
@@ -613,7 +637,7 @@ public:
         const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
         const bool lane_key = tagged && alg == kAlgSW && key_top <= 32000;
         const bool affine_sym = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
-        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? (affine_sym ? 6 : 2) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
+        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? (affine_tagged ? (affine_sym ? 8 : 7) : (affine_sym ? 6 : 2)) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -666,7 +690,7 @@ public:
             t.gap_ref = f.gap_ref;
             t.affine = sc_.affine ? 1 : 0;
             t.sse_policy = sse_policy_ ? 1 : 0;
-            t.tagged = tagged ? 1 : 0;
+            t.tagged = affine_tagged ? 2 : (tagged ? 1 : 0);
             t.open_read = f.open_read;
             t.ext_read = f.ext_read;
             t.open_ref = f.open_ref;

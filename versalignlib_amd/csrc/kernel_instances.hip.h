@@ -47,6 +47,10 @@
     PREFIX __global__ void align_fill_affine_kernel<G, K, kAlgNW, true>(const FillArgs);             \
     PREFIX __global__ void align_fill_sse_kernel<G, K, kAlgSW>(const FillArgs);                      \
     PREFIX __global__ void align_fill_sse_kernel<G, K, kAlgNW>(const FillArgs);                      \
+    PREFIX __global__ void align_fill_affine_tag_kernel<G, K, kAlgSW, false>(const FillArgs);        \
+    PREFIX __global__ void align_fill_affine_tag_kernel<G, K, kAlgSW, true>(const FillArgs);         \
+    PREFIX __global__ void align_fill_affine_tag_kernel<G, K, kAlgNW, false>(const FillArgs);        \
+    PREFIX __global__ void align_fill_affine_tag_kernel<G, K, kAlgNW, true>(const FillArgs);         \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, false>(const FillArgs);               \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, true>(const FillArgs);                \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgNW, false>(const FillArgs);

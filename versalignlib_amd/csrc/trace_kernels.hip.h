@@ -299,6 +299,53 @@ align_fill_kernel(const FillArgs args) {
     write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
 }
 
+// Pointer words leave the lane in bursts of whole 32-byte sectors: a lane's K dwords per block (40 bytes at
+// K = 10) dirty partial sectors, L2 evicts them half written and the HBM write traffic comes out 1.7x the
+// useful bytes (PMC WRITE_SIZE / TCC_EA0_WRREQ) -- and these kernels run against the write path.  kHoldBlocks
+// consecutive blocks (contiguous in the lane's region) are therefore kept in registers and stored together
+// as 16-byte words: 160 bytes = five full sectors at K = 10.
+constexpr int hold_blocks(int K) {
+    int g = 8, k = K;
+    while (k) { const int r = g % k; g = k; k = r; }      // gcd(K, 8)
+    return 8 / g;
+}
+
+template <int K, int NB>
+__device__ __forceinline__ void store_held_blocks(unsigned *dst, const s16x2 (&hold)[(NB > 1 ? NB - 1 : 1) * K], const s16x2 (&acc)[K]) {
+    unsigned w[NB * K];
+#pragma unroll
+    for (int i = 0; i < (NB - 1) * K; ++i) w[i] = as_u32(hold[i]);
+#pragma unroll
+    for (int q = 0; q < K; ++q) w[(NB - 1) * K + q] = as_u32(acc[q]);
+    static_assert(NB == 1 || (NB * K) % 4 == 0, "a burst is a whole number of 16-byte words");
+#pragma unroll
+    for (int i = 0; i < NB * K / 4; ++i)
+        reinterpret_cast<uint4 *>(dst)[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// block `b` (wave-uniform) of a burst is complete: park it, or store the whole burst with it
+template <int K, int NB>
+__device__ __forceinline__ void finish_block(unsigned *lane_base, long long block, s16x2 (&hold)[(NB > 1 ? NB - 1 : 1) * K],
+                                             const s16x2 (&acc)[K]) {
+    if constexpr (NB == 1) {
+        unsigned *dst = lane_base + block * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+        return;
+    }
+    const int b = (int)(block % NB);
+    if (b == NB - 1) {
+        store_held_blocks<K, NB>(lane_base + (block - (NB - 1)) * K, hold, acc);
+    } else {
+#pragma unroll
+        for (int x = 0; x < NB - 1; ++x)
+            if (b == x) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) hold[x * K + q] = acc[q];
+            }
+    }
+}
+
 // Linear gaps, Default tie-breaks, with the back pointer carried INSIDE the cell value: every value
 // is kept as 4 * H + tag, tag 2 for the diagonal candidate (folded into the query profile: 4 * S + 2),
 // 1 for the candidate from above (folded into the gap constant), 0 for the one from the left.  One
@@ -352,7 +399,10 @@ align_fill_tag_kernel(const FillArgs args) {
         jr[half] = w.first_bad[2 * p_local + 1];
     }
 
-    s16x2 Hl[K], tag[K], acc[K];
+    // (one block per store here: this kernel is bound by VALU issue, and parking blocks costs more moves than
+    // the fuller sectors save -- measured 18.1 vs 18.6 ms; the 4-step blocks of the affine kernel do gain)
+    constexpr int kHold = 1;
+    s16x2 Hl[K], tag[K], acc[K], hold[K];
     constexpr int kTracked = (ALG == kAlgSW && !LANEKEY) ? K : 1;
     s16x2 rb[kTracked], fc[kTracked], sel[ALG == kAlgNW ? K : 1];
     s16x2 row_key[LANEKEY ? K : 1];              // 2^b - 1 - q: the earlier row wins among equal values
@@ -485,16 +535,13 @@ align_fill_tag_kernel(const FillArgs args) {
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, tag[q]);
-        if ((t & 7) == 7) {
-            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
-#pragma unroll
-            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
-        }
+        if ((t & 7) == 7) finish_block<K, kHold>(ptr_lane, t >> 3, hold, acc);
         ++j;
         code_addr += 2;
     };
 
-    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;
+    // whole bursts: args.blocks8 is a multiple of kHold (hip_engine.hip.h)
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 8 * kHold - 1) / (8 * kHold)) * (8 * kHold) : args.blocks8 * 8;
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
     int t = 0;
@@ -700,6 +747,206 @@ align_fill_affine_kernel(const FillArgs args) {
 }
 
 
+// Affine gaps with everything the traceback needs carried in the low bits of the cell values (the
+// affine counterpart of align_fill_tag_kernel).  All values are 8 * x + tag:
+//   E / F candidates: bit 0 = 1 on "opened from H" (folded into the open constant), 0 on "extended" --
+//     one maximum picks the value and, on ties, the open, as the equality-test kernel does;
+//   H candidates: bits 2..1 = 2 on the diagonal term (folded into the query profile: 8 * S + 4), 1 on
+//     F (one add), 0 on E -- one maximum chain resolves DIAG > F > E on ties whatever bit 0 holds.
+// `x & ~7` cleans a value for reuse, and one 4-bit code per cell -- source of H, E opened, F opened --
+// is three bit operations and a multiply-add away.  18 packed instructions per register instead of
+// 22; the pointer stream is K dwords per lane and 4-step block (same volume as before).
+// SYM: open_read == open_ref and ext_read == ext_ref, `H + open` shared by E and F.
+template <int G, int K, int ALG, bool SYM>
+__global__ void __launch_bounds__(256)
+align_fill_affine_tag_kernel(const FillArgs args) {
+    using geo = Geo<G, K>;
+    constexpr bool LANEKEY = ALG == kAlgSW;
+    constexpr int kKeyBits = K <= 16 ? 4 : 5;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / G;
+    const int l = lane % G;
+    const int R = args.R;
+    const int pad_rows = geo::kRows - R;
+
+    WaveTables w;
+    if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
+                                args.wave_lds, (short)(8 * args.match + 4), (short)(8 * args.mismatch + 4), w, false,
+                                blockIdx.x, (short)4))
+        return;
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+
+    const unsigned lmask = l == 0 ? 0u : 0xFFFFFFFFu;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    unsigned code_addr = lds_offset(w.refc) + grp * args.refc_stride - 2 * l;
+
+    // SW: magnitudes for the unsigned floor-at-zero subtract (the open constants one short: the result carries
+    // tag 1); NW: signed saturating addends
+    s16x2 x_read, x_ref, o_read, o_ref;
+    if (ALG == kAlgSW) {
+        x_read = pk((short)(-8 * args.ext_read));      x_ref = pk((short)(-8 * args.ext_ref));
+        o_read = pk((short)(-8 * args.open_read - 1)); o_ref = pk((short)(-8 * args.open_ref - 1));
+    } else {
+        x_read = pk((short)(8 * args.ext_read));       x_ref = pk((short)(8 * args.ext_ref));
+        o_read = pk((short)(8 * args.open_read + 1));  o_ref = pk((short)(8 * args.open_ref + 1));
+    }
+    constexpr short kMinusInf = -30000;                // multiple of 8, far below any real cell, room to saturate
+    const s16x2 border_f = pk(ALG == kAlgNW ? kMinusInf : (short)0);
+    s16x2 two = pk(2), sixteen = pk(16), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 3)));
+    unsigned clean_mask = 0xFFF8FFF8u, src_mask = 0x00060006u, one_mask = 0x00010001u;
+    asm volatile("" : "+v"(two), "+v"(sixteen), "+v"(fifteen), "+v"(key_mul), "+v"(clean_mask), "+v"(src_mask), "+v"(one_mask));
+
+    auto gap_add = [](s16x2 v, s16x2 c) __attribute__((always_inline)) {
+        return (ALG == kAlgSW) ? pk_sub_floor0(v, c) : pk_add_sat(v, c);
+    };
+
+    int ir[2], jr[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int p_local = 2 * grp + half;
+        p_local = p_local > w.last ? w.last : p_local;
+        ir[half] = w.first_bad[2 * p_local];
+        jr[half] = w.first_bad[2 * p_local + 1];
+    }
+
+    constexpr int kHold = hold_blocks(K);
+    s16x2 Hl[K], El[K], HOl[SYM ? K : 1], code[K], acc[K], hold[(kHold > 1 ? kHold - 1 : 1) * K];
+    s16x2 rb[1], fc[1], sel[ALG == kAlgNW ? K : 1], row_key[LANEKEY ? K : 1];
+    short nw_seed[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const int p = l * K + q;
+        short border = 0;
+        if (ALG == kAlgNW)                         // column 0: a gap of i bases in the ref direction (times 8)
+            border = p < pad_rows ? (short)0 : (short)(8 * (args.open_ref + (p - pad_rows) * args.ext_ref));
+        Hl[q] = pk(border);
+        if (SYM) HOl[q] = gap_add(Hl[q], o_read);
+        El[q] = border_f;
+        code[q] = acc[q] = pk(0);
+        if (ALG == kAlgSW) {
+            row_key[q] = pk((short)((1 << kKeyBits) - 1 - q));
+            asm volatile("" : "+v"(row_key[q]));
+        } else {
+            const bool ta = ir[0] >= 1 && p == ir[0] - 1 + pad_rows;
+            const bool tb = ir[1] >= 1 && p == ir[1] - 1 + pad_rows;
+            sel[q] = s16x2{(short)(ta ? 1 : 0), (short)(tb ? 1 : 0)};
+            if (ta) nw_seed[0] = border;
+            if (tb) nw_seed[1] = border;
+        }
+    }
+    rb[0] = pk(0);
+    fc[0] = pk(0);
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};
+        fc[0] = pk((short)l);
+    }
+    s16x2 h_last = Hl[K - 1], f_last = border_f;
+    s16x2 up0 = pk(0);
+    int j = -l;
+
+    const long long pp = w.pair0 / 2 + grp;
+    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;     // blocks8: 4-step blocks here
+
+    unsigned pa[K / 2], pb[K / 2];
+    unsigned ca_next, cb_next;
+    {
+        const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 2);
+        cb_next = *(lds_cu8 *)(code_addr + 3);
+    }
+
+    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const s16x2 diag0 = up0;
+        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        const unsigned fv = from_prev_lane(as_u32(f_last));
+        const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        s16x2 S[K];
+        merge_profile<K>(pa, pb, S);
+        lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+        ca_next = *(lds_cu8 *)(code_addr + 4);
+        cb_next = *(lds_cu8 *)(code_addr + 5);
+        if (!MASKED || (unsigned)j < (unsigned)F) {
+            const s16x2 tt = pk((short)t);
+            // pass1(q): everything of row q that only needs the previous column, one row ahead of the chain
+            s16x2 d_cur, e_cur;
+            auto pass1 = [&](int q, s16x2 &d_t, s16x2 &e_t) __attribute__((always_inline)) {
+                d_t = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                                     // tag 4: DIAG
+                const s16x2 e_ext = gap_add(El[q], x_read);                                    // bit 0 = 0: extended
+                const s16x2 e_opn = SYM ? HOl[q] : gap_add(Hl[q], o_read);                     // bit 0 = 1: opened
+                e_t = pk_max(e_ext, e_opn);
+                El[q] = as_pk(as_u32(e_t) & clean_mask);
+            };
+            s16x2 hc = up0, fcl = fup0;                      // clean H / F of the row above
+            s16x2 ho = gap_add(up0, o_ref);                  // its H + open (bit 0 = 1)
+            s16x2 hs = pk(0), step_key = pk(0);
+            pass1(0, d_cur, e_cur);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 f_ext = gap_add(fcl, x_ref);
+                const s16x2 f_t = pk_max(f_ext, ho);
+                s16x2 d_next = pk(0), e_next = pk(0);
+                if (q + 1 < K) pass1(q + 1, d_next, e_next);                 // before Hl[q] is overwritten
+                fcl = as_pk(as_u32(f_t) & clean_mask);
+                const s16x2 f_h = f_t + two;                                  // bits 2..1 = 1: from F
+                const s16x2 h_t = pk_max(pk_max(d_cur, f_h), e_cur);
+                hc = as_pk(as_u32(h_t) & clean_mask);
+                Hl[q] = hc;
+                ho = gap_add(hc, o_ref);
+                if (SYM) HOl[q] = ho;
+                // 4-bit code: [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
+                const unsigned src_e = (as_u32(e_cur) & one_mask) | (as_u32(h_t) & src_mask);
+                code[q] = pk_mad_u(as_pk(src_e), two, as_pk(as_u32(f_t) & one_mask));
+                if (ALG == kAlgSW) {
+                    step_key = pk_max(step_key, pk_mad_u(hc, key_mul, row_key[q]));
+                } else {
+                    unsigned v = as_u32(pk_mad_u(hc, sel[q], hs));
+                    asm volatile("" : "+v"(v));
+                    hs = as_pk(v);
+                }
+                d_cur = d_next;
+                e_cur = e_next;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ALG == kAlgSW) {
+                const s16x2 changed = (rb[0] - step_key) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = pk_max(rb[0], step_key);
+            } else {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = hc;
+            f_last = fcl;
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], sixteen, code[q]);
+        if ((t & 3) == 3) finish_block<K, kHold>(ptr_lane, t >> 2, hold, acc);
+        ++j;
+        code_addr += 2;
+    };
+
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 4 * kHold - 1) / (4 * kHold)) * (4 * kHold) : args.blocks8 * 4;
+    const int fill_end = G - 1 < steps ? G - 1 : steps;
+    const int steady_end = F > fill_end ? F : fill_end;
+    int t = 0;
+    for (; t < fill_end; ++t) step(std::true_type{}, t);
+    for (; t + 1 < steady_end; t += 2) {
+        step(std::false_type{}, t);
+        step(std::false_type{}, t + 1);
+    }
+    for (; t < steady_end; ++t) step(std::false_type{}, t);
+    for (; t < steps; ++t) step(std::true_type{}, t);
+
+    if constexpr (LANEKEY) write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
+    else write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
+}
+
 // Second tie-break policy: the reference's SSE2/AVX2 kernels (SSEKernel.cpp:366-379, 646-659).
 // Stored states: 0 START, 1 UP, 2 LEFT, 3 DIAG; DIAG only between two ACGT bases, then LEFT, then UP,
 // else START -- no "cell == 0 -> START" rule.  Cells are computed in the signed form (the equality
@@ -862,7 +1109,8 @@ struct TraceArgs {
     int alg;
     int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
     int sse_policy;           // 1: stored states are 0 START, 1 UP, 2 LEFT, 3 DIAG (SSE/AVX kernel rules)
-    int tagged;               // 1: codes are the tags of align_fill_tag_kernel (2 DIAG, 1 UP, 0 LEFT)
+    int tagged;               // 1: codes are the tags of align_fill_tag_kernel (2 DIAG, 1 UP, 0 LEFT);
+                              // 2: 4-bit codes of align_fill_affine_tag_kernel, K words per 4-step block
     short match, mismatch, gap_read, gap_ref;
     short open_read, ext_read, open_ref, ext_ref;
 };
@@ -878,7 +1126,7 @@ traceback_kernel(const TraceArgs a) {
     const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= a.n) return;
     const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
-    const int wpb = a.affine ? 2 * K : K;                         // words per lane and 8-step block
+    const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;      // words per lane and block of steps
     const uint8_t *read = a.reads + pair * R;
     const uint8_t *ref = a.refs + pair * F;
     uint8_t *row_read = a.rows + pair * 2 * AL;
@@ -928,6 +1176,7 @@ traceback_kernel(const TraceArgs a) {
         }
         const int sel = (int)(wi & 3);
         const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
+        if (a.tagged == 2) return (int)((word >> (half_shift + 4 * (3 - (t & 3)))) & 15u);
         return (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
     };
 
@@ -949,8 +1198,25 @@ traceback_kernel(const TraceArgs a) {
             const int p = i + a.pad_rows;
             const int l = p / K, q = p - l * K;
             const int t = j + l;
-            const long long wi = ((long long)l * a.blocks8 + (t >> 3)) * wpb + q;
-            if (a.sse_policy) {
+            const long long wi = ((long long)l * a.blocks8 + (a.tagged == 2 ? (t >> 2) : (t >> 3))) * wpb + q;
+            if (a.tagged == 2) {
+                const int f4 = code_at(wi, t);          // [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
+                if (state == 0) {
+                    const int src = f4 >> 2;
+                    move = src == 2 ? 0 : (src == 1 ? 1 : 2);
+                    if (move != 0) {
+                        state = move;                   // nothing is emitted on entering a gap state
+                        continue;
+                    }
+                } else {
+                    move = state;
+                    if (state == 1) {
+                        if (f4 & 1) { h -= a.open_ref; state = 0; } else h -= a.ext_ref;
+                    } else {
+                        if (f4 & 2) { h -= a.open_read; state = 0; } else h -= a.ext_read;
+                    }
+                }
+            } else if (a.sse_policy) {
                 const int st = code_at(wi, t);          // 0 START, 1 UP, 2 LEFT, 3 DIAG
                 if (st == 0) break;
                 move = st == 3 ? 0 : st;
