@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1 << 20)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--geoms", default="0x0")
+    ap.add_argument("--policy", type=int, default=0, help="1: SSE/AVX tie-breaks")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     reads, refs = bench.synth_on_device(a.pairs, dev, seed=2000)
@@ -25,6 +26,8 @@ def main():
     for geom in a.geoms.split(","):
         G, K = (int(x) for x in geom.split("x"))
         eng = hipkernel.Engine(bench.R, bench.F, group_lanes=G, rows_per_lane=K)
+        if a.policy:
+            eng.set_traceback_policy(a.policy)
         for opt, name in ((0, "sw"), (1, "nw")):
             eng.align_device(opt, reads, refs, rows, idx)
             torch.cuda.synchronize()

@@ -51,10 +51,11 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][7];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][9];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+    const void *fill[2][11];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
                                    //                               linear with the pointer tagged into the cell, the same with
                                    //                               one end-cell key per lane (SW), symmetric affine,
-                                   //                               affine / symmetric affine with tagged cells]
+                                   //                               affine / symmetric affine with tagged cells,
+                                   //                               SSE policy with tagged cells (per-row / lane key)]
 };
 
 template <int G, int K>
@@ -76,17 +77,20 @@ constexpr Geometry make_geometry() {
                       (const void *)&score_kernel<G, K, kAlgNW, kGapSymF16>}},
                     {{(const void *)&align_fill_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgSW>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false, false>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true, false>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, false>,
-                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, true>},
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, true>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false, true>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true, true>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false>, nullptr,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, false>, nullptr,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, false>,
-                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, true>}}};
+                      (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, true>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, true>, nullptr}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -439,7 +443,7 @@ public:
         const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
         const int worst = std::min({sc_.gap_read, sc_.gap_ref, sc_.mismatch, 0});
         const long long lo = alg == kAlgSW ? worst : (long long)(R_ + F_ + 2) * worst;      // H(i,j) >= i gf + j gr
-        if (alg == kAlgSW && sc_.gap_ref >= 0) return false;
+        if (alg == kAlgSW && !sse_policy_ && sc_.gap_ref >= 0) return false;
         return 4 * hi + 4 <= 32000 && 4 * lo - 4 >= -32000 && std::abs(sc_.match) < 2000 && std::abs(sc_.mismatch) < 2000;
     }
 
@@ -631,13 +635,13 @@ public:
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
         // linear gaps, Default tie-breaks: the pointer rides in the low bits of the cell where 4x the cell
         // range still fits int16 (and, for SW, gap_ref < 0); otherwise the equality-test kernels
-        const bool tagged = !sse_policy_ && !sc_.affine && !no_tag_ && tagged_range_ok(alg);
+        const bool tagged = !sc_.affine && !no_tag_ && tagged_range_ok(alg);        // (both tie-break policies)
         // SW: one (value, row) key per lane instead of a first-arg-max per row where value << 4 (5 bits of
         // row for more than 16 rows per lane) still fits int16
         const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
         const bool lane_key = tagged && alg == kAlgSW && key_top <= 32000;
         const bool affine_sym = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
-        const void *fn = plan_.geo->fill[alg][tagged ? (lane_key ? 5 : 4) : (sse_policy_ ? 3 : (sc_.affine ? (affine_tagged ? (affine_sym ? 8 : 7) : (affine_sym ? 6 : 2)) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
+        const void *fn = plan_.geo->fill[alg][tagged ? (sse_policy_ ? (lane_key ? 10 : 9) : (lane_key ? 5 : 4)) : (sse_policy_ ? 3 : (sc_.affine ? (affine_tagged ? (affine_sym ? 8 : 7) : (affine_sym ? 6 : 2)) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -690,7 +694,7 @@ public:
             t.gap_ref = f.gap_ref;
             t.affine = sc_.affine ? 1 : 0;
             t.sse_policy = sse_policy_ ? 1 : 0;
-            t.tagged = affine_tagged ? 2 : (tagged ? 1 : 0);
+            t.tagged = affine_tagged ? 2 : ((tagged && !sse_policy_) ? 1 : 0);     // SSE tags are the stored states
             t.open_read = f.open_read;
             t.ext_read = f.ext_read;
             t.open_ref = f.open_ref;

@@ -359,7 +359,12 @@ __device__ __forceinline__ void finish_block(unsigned *lane_base, long long bloc
 // `value << b | (2^b - 1 - row)` -- larger value first, then the earlier row -- and the step at which
 // it last grew: a multiply-add and a maximum per register plus four instructions per step.  Needs
 // value << b to stay in int16 (the engine checks).
-template <int G, int K, int ALG, bool LANEKEY>
+// SSE: the tie-breaks of the reference's SSE2/AVX2 kernels instead (SSEKernel.cpp:366-379, 646-659): DIAG only
+// between two ACGT bases > LEFT > UP, else START, and no "cell == 0 -> START" rule.  The tags ARE the stored
+// states then -- 3 on a valid diagonal (profile 4 * S + 3), 0 on an invalid one (profile 0), 2 on the
+// candidate from the left, 1 on the one from above, 0 on the SW floor -- cells are computed in the signed form
+// (the floor is an explicit maximum) and N counts as invalid for the NW end cell.
+template <int G, int K, int ALG, bool LANEKEY, bool SSE>
 __global__ void __launch_bounds__(256)
 align_fill_tag_kernel(const FillArgs args) {
     static_assert(!LANEKEY || ALG == kAlgSW, "the lane key replaces the Smith-Waterman row arg-max");
@@ -372,9 +377,10 @@ align_fill_tag_kernel(const FillArgs args) {
     const int pad_rows = geo::kRows - R;
 
     WaveTables w;
+    constexpr int kDiagTag = SSE ? 3 : 2;
     if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                args.wave_lds, (short)(4 * args.match + 2), (short)(4 * args.mismatch + 2), w, false,
-                                blockIdx.x, (short)2))
+                                args.wave_lds, (short)(4 * args.match + kDiagTag), (short)(4 * args.mismatch + kDiagTag), w, SSE,
+                                blockIdx.x, (short)(SSE ? 0 : 2)))
         return;
     const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
@@ -384,8 +390,10 @@ align_fill_tag_kernel(const FillArgs args) {
 
     // SW: magnitudes for the unsigned floor-at-zero subtract (4|g| from the left, 4|g| - 1 from above: the
     // result carries tag 1); NW: signed addends 4g and 4g + 1
-    const s16x2 g_read = pk(ALG == kAlgSW ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read));
-    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
+    // (SSE: signed addends in both modes, LEFT carries tag 2 and UP tag 1)
+    constexpr bool kUnsignedGaps = ALG == kAlgSW && !SSE;
+    const s16x2 g_read = pk(kUnsignedGaps ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read + (SSE ? 2 : 0)));
+    const s16x2 g_ref = pk(kUnsignedGaps ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
     s16x2 four = pk(4), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 2)));     // cells are 4 * H already
     unsigned tag_mask = 0x00030003u;
     asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul));
@@ -478,7 +486,7 @@ align_fill_tag_kernel(const FillArgs args) {
             // is needed, so it is computed one row ahead, between the links of the dependent chain
             auto pass1 = [&](int q) __attribute__((always_inline)) -> s16x2 {
                 const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                               // tag 2
-                const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;   // tag 0
+                const s16x2 e = kUnsignedGaps ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;      // tag 0 (SSE: 2)
                 return pk_max(d, e);
             };
             s16x2 h = up0;
@@ -505,10 +513,11 @@ align_fill_tag_kernel(const FillArgs args) {
             s16x2 m_cur = pass1(0);
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const s16x2 f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;              // tag 1
+                const s16x2 f = kUnsignedGaps ? pk_sub_floor0(h, g_ref) : h + g_ref;                 // tag 1
                 s16x2 m_next = pk(0);
                 if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] is overwritten
-                const s16x2 ht = pk_max(m_cur, f);
+                s16x2 ht = pk_max(m_cur, f);
+                if (SSE && ALG == kAlgSW) ht = pk_max(ht, pk(0));              // the floor is START (tag 0)
                 if (q > 0) finish_row(q - 1, h_prev);
                 tag[q] = as_pk(as_u32(ht) & tag_mask);
                 h = as_pk(as_u32(ht) & ~tag_mask);
