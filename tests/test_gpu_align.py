@@ -279,3 +279,32 @@ def test_host_malloc_tuning_key_changes_nothing_but_the_allocator():
         for _ in range(2):                                    # second call recycles the first call's blocks
             got = hip.compute_alignments(host.SW, reads, refs, normalise=False)
         _assert_same(got, cpu_ref.align(host.SW, reads, refs, threads=8), "tuned")
+
+
+@pytest.mark.parametrize("kind", ["linear", "linear_asym", "sse", "affine", "affine_asym"])
+def test_equality_test_kernels_stay_correct(monkeypatch, kind):
+    """The tagged-cell kernels are the default; beyond their int16 headroom the engine falls back to the
+    kernels that derive pointers by equality tests.  VALIGN_HIP_NO_TAG forces that path: same alignments."""
+    import torch
+    monkeypatch.setenv("VALIGN_HIP_NO_TAG", "1")
+    R, F, n = 150, 500, 700
+    reads, refs = _data(R, F, n, 97)
+    kw, policy, gaps = {}, "default", (-3, -3)
+    if kind == "linear_asym":
+        gaps = (-2, -4)
+    elif kind == "affine":
+        kw = dict(open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
+    elif kind == "affine_asym":
+        kw = dict(open_read=-5, ext_read=-1, open_ref=-4, ext_ref=-2)
+    elif kind == "sse":
+        policy = "sse"
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, gaps[0], gaps[1], **kw))
+    if policy == "sse":
+        eng.set_traceback_policy(1)
+    osc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1], **kw)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    for opt in (host.SW, host.NW):
+        rows, idx = eng.align_device(opt, d_reads, d_refs)
+        exp = cpu_ref.align(opt, reads, refs, osc, threads=8, affine=bool(kw), policy=policy)
+        _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), exp, (kind, opt))
+    eng.close()
