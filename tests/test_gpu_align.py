@@ -308,3 +308,22 @@ def test_equality_test_kernels_stay_correct(monkeypatch, kind):
         exp = cpu_ref.align(opt, reads, refs, osc, threads=8, affine=bool(kw), policy=policy)
         _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), exp, (kind, opt))
     eng.close()
+
+
+def test_scores_beyond_the_tag_headroom_take_the_fallback_kernels():
+    """match 60 at 150 x 500: cells reach 9 000, four (eight) times that no longer fits int16, so the engine
+    must pick the equality-test kernels by itself -- linear and affine, both modes."""
+    import torch
+    R, F, n = 150, 500, 400
+    reads, refs = _data(R, F, n, 98)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    for kw in ({}, dict(open_read=-70, ext_read=-20, open_ref=-70, ext_ref=-20)):
+        eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(60, -40, -50, -50, **kw))
+        osc = cpu_ref.Scoring.make(60, -40, -50, -50, **kw)
+        for opt in (host.SW, host.NW):
+            rows, idx = eng.align_device(opt, d_reads, d_refs)
+            exp = cpu_ref.align(opt, reads, refs, osc, threads=8, affine=bool(kw))
+            _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), exp, (bool(kw), opt))
+            assert np.array_equal(eng.score_device(opt, d_reads, d_refs).cpu().numpy(),
+                                  cpu_ref.score(opt, reads, refs, osc, threads=8, affine=bool(kw)))
+        eng.close()
