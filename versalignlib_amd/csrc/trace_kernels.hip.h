@@ -466,8 +466,11 @@ align_fill_tag_kernel(const FillArgs args) {
         cb_next = *(lds_cu8 *)(code_addr + 3);
     }
 
-    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+    // LAST_ONLY (NW): every pair of the wave tracks its last padded row (full-length reads, the usual case):
+    // the arg-max bookkeeping then needs the last register only, not a multiply-add per register
+    auto step = [&](auto masked_tag, auto last_only_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool LAST_ONLY = decltype(last_only_tag)::value;
         const s16x2 diag0 = up0;
         if (G == 16) {
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
@@ -505,9 +508,11 @@ align_fill_tag_kernel(const FillArgs args) {
                     // sel[q] is 1 in the half whose tracked row this is (one row per pair), else 0: a packed
                     // multiply-add picks that row's cell.  Pinned here: sunk to the end of the step pair (where
                     // the optimiser wants it) every clean cell is rematerialised for it.
-                    unsigned v = as_u32(pk_mad_u(hq, sel[q], hs));
-                    asm volatile("" : "+v"(v));
-                    hs = as_pk(v);
+                    if (!LAST_ONLY || q == K - 1) {
+                        unsigned v = as_u32(pk_mad_u(hq, sel[q], hs));
+                        asm volatile("" : "+v"(v));
+                        hs = as_pk(v);
+                    }
                 }
             };
             s16x2 m_cur = pass1(0);
@@ -553,14 +558,25 @@ align_fill_tag_kernel(const FillArgs args) {
     const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 8 * kHold - 1) / (8 * kHold)) * (8 * kHold) : args.blocks8 * 8;
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
-    int t = 0;
-    for (; t < fill_end; ++t) step(std::true_type{}, t);
-    for (; t + 1 < steady_end; t += 2) {
-        step(std::false_type{}, t);
-        step(std::false_type{}, t + 1);
+    auto sweep = [&](auto last_only_tag) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t < fill_end; ++t) step(std::true_type{}, last_only_tag, t);
+        for (; t + 1 < steady_end; t += 2) {
+            step(std::false_type{}, last_only_tag, t);
+            step(std::false_type{}, last_only_tag, t + 1);
+        }
+        for (; t < steady_end; ++t) step(std::false_type{}, last_only_tag, t);
+        for (; t < steps; ++t) step(std::true_type{}, last_only_tag, t);
+    };
+    bool last_only = false;
+    if (ALG == kAlgNW) {
+        bool mine = true;
+#pragma unroll
+        for (int q = 0; q + 1 < K; ++q) mine = mine && as_u32(sel[q]) == 0u;
+        last_only = __all(mine);
     }
-    for (; t < steady_end; ++t) step(std::false_type{}, t);
-    for (; t < steps; ++t) step(std::true_type{}, t);
+    if (last_only) sweep(std::true_type{});
+    else sweep(std::false_type{});
 
     if constexpr (LANEKEY) write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
     else write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
@@ -866,8 +882,11 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         cb_next = *(lds_cu8 *)(code_addr + 3);
     }
 
-    auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
+    // LAST_ONLY (NW): every pair of the wave tracks its last padded row (full-length reads, the usual case):
+    // the arg-max bookkeeping then needs the last register only, not a multiply-add per register
+    auto step = [&](auto masked_tag, auto last_only_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool LAST_ONLY = decltype(last_only_tag)::value;
         const s16x2 diag0 = up0;
         up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         const unsigned fv = from_prev_lane(as_u32(f_last));
@@ -912,9 +931,11 @@ align_fill_affine_tag_kernel(const FillArgs args) {
                 if (ALG == kAlgSW) {
                     step_key = pk_max(step_key, pk_mad_u(hc, key_mul, row_key[q]));
                 } else {
-                    unsigned v = as_u32(pk_mad_u(hc, sel[q], hs));
-                    asm volatile("" : "+v"(v));
-                    hs = as_pk(v);
+                    if (!LAST_ONLY || q == K - 1) {
+                        unsigned v = as_u32(pk_mad_u(hc, sel[q], hs));
+                        asm volatile("" : "+v"(v));
+                        hs = as_pk(v);
+                    }
                 }
                 d_cur = d_next;
                 e_cur = e_next;
@@ -943,14 +964,25 @@ align_fill_affine_tag_kernel(const FillArgs args) {
     const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 4 * kHold - 1) / (4 * kHold)) * (4 * kHold) : args.blocks8 * 4;
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
-    int t = 0;
-    for (; t < fill_end; ++t) step(std::true_type{}, t);
-    for (; t + 1 < steady_end; t += 2) {
-        step(std::false_type{}, t);
-        step(std::false_type{}, t + 1);
+    auto sweep = [&](auto last_only_tag) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t < fill_end; ++t) step(std::true_type{}, last_only_tag, t);
+        for (; t + 1 < steady_end; t += 2) {
+            step(std::false_type{}, last_only_tag, t);
+            step(std::false_type{}, last_only_tag, t + 1);
+        }
+        for (; t < steady_end; ++t) step(std::false_type{}, last_only_tag, t);
+        for (; t < steps; ++t) step(std::true_type{}, last_only_tag, t);
+    };
+    bool last_only = false;
+    if (ALG == kAlgNW) {
+        bool mine = true;
+#pragma unroll
+        for (int q = 0; q + 1 < K; ++q) mine = mine && as_u32(sel[q]) == 0u;
+        last_only = __all(mine);
     }
-    for (; t < steady_end; ++t) step(std::false_type{}, t);
-    for (; t < steps; ++t) step(std::true_type{}, t);
+    if (last_only) sweep(std::true_type{});
+    else sweep(std::false_type{});
 
     if constexpr (LANEKEY) write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
     else write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
