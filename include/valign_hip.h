@@ -32,6 +32,10 @@
  *                                                         calls are recycled instead of trimmed and re-faulted
  *                                                         (changes the host's allocator; default 0)
  *       hip_device ...................................... device ordinal (default 0)
+ *       hip_devices ..................................... N > 1: every call is split into N contiguous shards of
+ *                                                         pairs, one per device (hip_device .. hip_device+N-1,
+ *                                                         modulo the visible ones), each on its own host thread;
+ *                                                         results land in the caller's arrays (default 1)
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
  * (2) A flat C view of the same engine for callers that already hold the batch in

@@ -327,3 +327,18 @@ def test_scores_beyond_the_tag_headroom_take_the_fallback_kernels():
             assert np.array_equal(eng.score_device(opt, d_reads, d_refs).cpu().numpy(),
                                   cpu_ref.score(opt, reads, refs, osc, threads=8, affine=bool(kw)))
         eng.close()
+
+
+def test_in_plugin_device_shards():
+    """hip_devices = N splits every call into N contiguous shards, one engine (device modulo the visible
+    ones, so a one-GPU box runs them all on device 0) and host thread each: same scores and alignments."""
+    R, F, n = 150, 500, 10007
+    reads, refs = _data(R, F, n, 99)
+    exp_scores = cpu_ref.score(host.SW, reads, refs, threads=8)
+    exp = cpu_ref.align(host.NW, reads, refs, threads=8)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=6, hip_devices=3) as hip:
+        assert np.array_equal(hip.score_alignments(host.SW, reads, refs), exp_scores)
+        _assert_same(hip.compute_alignments(host.NW, reads, refs, normalise=False), exp, "3 shards")
+        assert np.array_equal(hip.score_alignments(host.SW, reads[:2], refs[:2]), exp_scores[:2])     # fewer pairs than shards
+    with pytest.raises(host.PluginError):
+        host.Plugin(build.HIP_PLUGIN, R, F, hip_devices=0)

@@ -12,6 +12,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "hip_engine.hip.h"
 
@@ -71,6 +73,21 @@ public:
             engine_->set_band_width(opt_param("band_width", 0));
             engine_->set_score_width(opt_param("score_width", 0));
             engine_->set_ragged_batching(opt_param("ragged_batching", 1));
+            // hip_devices = N: the pairs of every call are split into N contiguous shards, one device each
+            // (hip_device, hip_device + 1, ... modulo the visible devices), each shard on its own host
+            // thread with its own streams and staging.  Results land in the caller's host arrays, so no
+            // collective is needed inside one process.
+            const int shards = opt_param("hip_devices", 1);
+            if (shards < 1 || shards > 64) throw std::runtime_error("hip_devices must be 1..64");
+            const int first = opt_param("hip_device", 0), visible = valign_hip_device_count();
+            for (int d = 1; d < shards; ++d) {
+                more_.emplace_back(new valign::Engine((first + d) % (visible > 0 ? visible : 1), R, F, sc,
+                                                      opt_param("hip_group_lanes", 0), opt_param("hip_rows_per_lane", 0)));
+                more_.back()->set_traceback_policy(opt_param("traceback_policy", 0));
+                more_.back()->set_band_width(opt_param("band_width", 0));
+                more_.back()->set_score_width(opt_param("score_width", 0));
+                more_.back()->set_ragged_batching(opt_param("ragged_batching", 1));
+            }
             if (opt_param("host_malloc_tuning", 0) == 1) {
                 // compute_alignments must hand out 2n operator new[] blocks (the caller delete[]s them,
                 // include/AlignmentKernel.h:20-23).  At a million pairs glibc trims 1.4 GB back to the
@@ -100,7 +117,9 @@ public:
         log_line(0, "Running HIPKernel score with " + std::to_string(threads) + " host threads on " +
                         engine_->describe(opt, aln_number));
         try {
-            engine_->score_host(opt, aln_number, reads, refs, scores, threads);
+            sharded(aln_number, threads, [&](valign::Engine &e, int begin, int count, int th) {
+                e.score_host(opt, count, reads + begin, refs + begin, scores + begin, th);
+            });
             log_line(0, "HIPKernel score done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
             log_line(3, e.what());
@@ -115,7 +134,9 @@ public:
         log_line(0, "Running HIPKernel align with " + std::to_string(threads) + " host threads on " +
                         engine_->describe(opt, aln_number));
         try {
-            engine_->align_host(opt, aln_number, reads, refs, alignments, threads);
+            sharded(aln_number, threads, [&](valign::Engine &e, int begin, int count, int th) {
+                e.align_host(opt, count, reads + begin, refs + begin, alignments + begin, th);
+            });
             log_line(0, "HIPKernel align done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
             log_line(3, e.what());
@@ -124,7 +145,36 @@ public:
     }
 
 private:
+    // fn(engine, first pair, pairs, host threads) once per device shard, concurrently; the first error wins
+    template <typename Fn>
+    void sharded(int n, int threads, Fn fn) {
+        const int shards = 1 + (int)more_.size();
+        if (shards == 1 || n < shards) {
+            fn(*engine_, 0, n, threads);
+            return;
+        }
+        const int per = (n + shards - 1) / shards, th = threads / shards > 0 ? threads / shards : 1;
+        std::vector<std::exception_ptr> errors((size_t)shards);
+        std::vector<std::thread> workers;
+        for (int d = 0; d < shards; ++d) {
+            const int begin = d * per, count = begin < n ? (n - begin < per ? n - begin : per) : 0;
+            if (count <= 0) continue;
+            valign::Engine *e = d == 0 ? engine_.get() : more_[(size_t)d - 1].get();
+            workers.emplace_back([&, e, begin, count, d] {
+                try {
+                    fn(*e, begin, count, th);
+                } catch (...) {
+                    errors[(size_t)d] = std::current_exception();
+                }
+            });
+        }
+        for (auto &w : workers) w.join();
+        for (auto &err : errors)
+            if (err) std::rethrow_exception(err);
+    }
+
     std::unique_ptr<valign::Engine> engine_;
+    std::vector<std::unique_ptr<valign::Engine>> more_;      // hip_devices > 1: one engine per further device
     std::string what_;
 };
 
