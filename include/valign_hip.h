@@ -137,6 +137,13 @@ int valign_hip_align_device(valign_hip_engine *e, int opt, long long n, const vo
 int valign_hip_score_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
                           const char *const *refs, short *scores, int threads);
 
+/* compute_alignments for host pointers into caller-provided contiguous buffers: rows = n * 2 *
+ * (read_length + ref_length) bytes (read row, then ref row, per pair; zeros before the start, NUL at
+ * the end), idx = n * 4 shorts (readStart, readEnd, refStart, refEnd).  Same results as the plugin's
+ * compute_alignments without its 2n operator new[] blocks -- for FFI callers (ctypes, cgo, JNI).      */
+int valign_hip_align_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
+                          const char *const *refs, void *rows, short *idx, int threads);
+
 /* JSON description of what a call with this opt would launch (geometry, LDS, grid).   */
 int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap);
 

@@ -342,3 +342,13 @@ def test_in_plugin_device_shards():
         assert np.array_equal(hip.score_alignments(host.SW, reads[:2], refs[:2]), exp_scores[:2])     # fewer pairs than shards
     with pytest.raises(host.PluginError):
         host.Plugin(build.HIP_PLUGIN, R, F, hip_devices=0)
+
+
+def test_flat_host_entry_point_for_alignments():
+    """valign_hip_align_host: host pointers in, contiguous rows / idx out (no operator new[] blocks)."""
+    R, F, n = 150, 500, 9000
+    reads, refs = _data(R, F, n, 101)
+    eng = hipkernel.Engine(R, F)
+    for opt in (host.SW, host.NW):
+        _assert_same(eng.align_host(opt, reads, refs, threads=4), cpu_ref.align(opt, reads, refs, threads=8), ("flat", opt))
+    eng.close()

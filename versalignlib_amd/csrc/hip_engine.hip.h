@@ -292,6 +292,8 @@ public:
         ragged_ = mode;
     }
     int device() const { return device_; }
+    int read_length() const { return R_; }
+    int ref_length() const { return F_; }
     const LaunchPlan &plan() const { return plan_; }
     hipStream_t own_stream() const { return streams_[0]; }
 
@@ -713,8 +715,17 @@ public:
     // kSlots staging slots -- the 1.3 KB/pair result copy of chunk c, the kernels of chunk c+1 and the
     // input copy of chunk c+2 overlap, and the host gathers / scatters (2n operator new[] blocks, which
     // the ABI demands) meanwhile.
-    template <typename AlignmentT>
-    void align_host(int opt, int n, const char *const *reads, const char *const *refs, AlignmentT *alignments,
+    // `alignments`: the ABI's Alignment array (rows become operator new[] blocks), or a FlatSink (caller-provided
+    // contiguous buffers, for FFI callers that do not want 2n heap blocks)
+    struct FlatSink {
+        uint8_t *rows;            // n * 2 * (R+F) bytes
+        short *idx;               // n * 4
+        size_t AL;
+        FlatSink operator+(long long k) const { return FlatSink{rows + (size_t)k * 2 * AL, idx + 4 * k, AL}; }
+    };
+
+    template <typename Sink>
+    void align_host(int opt, int n, const char *const *reads, const char *const *refs, Sink alignments,
                     int threads) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;
@@ -925,6 +936,14 @@ private:
             hip_check(hipMalloc((void **)&d_idx_[s], sizeof(short) * 4 * (size_t)pairs), "hipMalloc");
         }
         align_staged_pairs_ = pairs;
+    }
+
+    void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
+        const size_t AL = sink.AL;
+        for_ranges(threads, cnt, 2048, [&](int, long long lo, long long hi) {
+            memcpy(sink.rows + (size_t)lo * 2 * AL, rows + (size_t)lo * 2 * AL, (size_t)(hi - lo) * 2 * AL);
+            memcpy(sink.idx + 4 * lo, idx + 4 * lo, sizeof(short) * 4 * (size_t)(hi - lo));
+        });
     }
 
     template <typename AlignmentT>

@@ -313,6 +313,18 @@ VALIGN_EXPORT int valign_hip_score_host(valign_hip_engine *e, int opt, int n, co
     return flat_guard([&] { e->impl->score_host(opt, n, reads, refs, scores, threads); });
 }
 
+VALIGN_EXPORT int valign_hip_align_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
+                                        const char *const *refs, void *rows, short *idx, int threads) {
+    if (!e || !rows || !idx) {
+        g_last_error = "null argument";
+        return 1;
+    }
+    return flat_guard([&] {
+        valign::Engine::FlatSink sink{(uint8_t *)rows, idx, (size_t)e->impl->read_length() + (size_t)e->impl->ref_length()};
+        e->impl->align_host(opt, n, reads, refs, sink, threads);
+    });
+}
+
 VALIGN_EXPORT int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap) {
     if (!e || !buf || cap <= 0) return 1;
     const std::string s = e->impl->describe(opt, n);

@@ -66,6 +66,7 @@ def lib():
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
         L.valign_hip_align_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp, vp]
         L.valign_hip_score_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int]
+        L.valign_hip_align_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
         L.valign_hip_describe.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_char_p,
                                           ctypes.c_int]
         L.valign_hip_last_error.restype = ctypes.c_char_p
@@ -76,7 +77,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_set_traceback_policy", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -173,6 +174,24 @@ class Engine:
         if rc != 0:
             raise HipKernelError(_err())
         return scores
+
+    def align_host(self, opt, reads, refs, threads=1):
+        """Host-pointer path of compute_alignments into contiguous numpy buffers (no operator new[] blocks):
+        -> rows uint8 [n, 2, R+F], idx int16 [n, 4]."""
+        import numpy as np
+        n = reads.shape[0]
+        assert reads.dtype == np.uint8 and refs.dtype == np.uint8 and reads.flags.c_contiguous and refs.flags.c_contiguous
+        assert tuple(reads.shape) == (n, self.read_length) and tuple(refs.shape) == (n, self.ref_length)
+        rp = (reads.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.read_length)).astype(np.uint64)
+        fp = (refs.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.ref_length)).astype(np.uint64)
+        AL = self.read_length + self.ref_length
+        rows = np.zeros((n, 2, AL), dtype=np.uint8)
+        idx = np.zeros((n, 4), dtype=np.int16)
+        rc = lib().valign_hip_align_host(self._h, int(opt), n, rp.ctypes.data, fp.ctypes.data, rows.ctypes.data,
+                                         idx.ctypes.data, int(threads))
+        if rc != 0:
+            raise HipKernelError(_err())
+        return rows, idx
 
     def describe(self, opt=0, n=0):
         buf = ctypes.create_string_buffer(2048)
