@@ -352,3 +352,24 @@ def test_flat_host_entry_point_for_alignments():
     for opt in (host.SW, host.NW):
         _assert_same(eng.align_host(opt, reads, refs, threads=4), cpu_ref.align(opt, reads, refs, threads=8), ("flat", opt))
     eng.close()
+
+
+@pytest.mark.parametrize("aff,order", [((-10, -6, -10, -6), (host.SW, host.NW)), ((0, -2, 0, -2), (host.NW, host.SW)),
+                                       ((-10, -6, -10, -6), (host.NW, host.SW))])
+def test_pointer_scratch_follows_the_widest_stream_of_an_engine(aff, order):
+    """One engine, same pair count, two modes whose fill kernels stream different byte counts per pair (tagged
+    4-step blocks vs untagged 8-step blocks with two code words): the scratch sized by the first call must grow
+    for the second (round-1 advisor finding: capacity was tracked in pairs, the second call wrote past it)."""
+    import torch
+    R, F, n = 150, 500, 4096
+    reads, refs = _data(R, F, n, 103)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
+    osc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    canary = torch.full((1 << 20,), 0x5A, dtype=torch.uint8, device="cuda")      # a neighbour allocation to trample
+    for opt in order + order:
+        rows, idx = eng.align_device(opt, d_reads, d_refs)
+        exp = cpu_ref.align(opt, reads, refs, osc, threads=8, affine=True)
+        _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), exp, (aff, opt))
+    assert bool((canary == 0x5A).all())
+    eng.close()

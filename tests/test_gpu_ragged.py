@@ -56,6 +56,7 @@ def test_ragged_affine_and_nw_untouched(small_bins):
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
     hsc = hipkernel.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
     eng = hipkernel.Engine(R, F, hsc)
+    eng.set_ragged_batching(1)
     got = eng.score_host(host.SW, reads, refs, threads=4)
     assert eng.describe()["ragged_launches"] > 1
     assert np.array_equal(got, cpu_ref.score(host.SW, reads, refs, sc, threads=8, affine=True))
@@ -73,8 +74,8 @@ def test_ragged_through_plugin_against_reference_sse(small_bins):
         pytest.skip("oracle/_ref not built")
     R, F, n = 150, 500, 4000
     reads, refs = synth.make_ragged_pairs(n, R, F, seed=47)
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as hip, host.Plugin(sse, R, F) as s, \
-            host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, ragged_batching=0) as off:
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, ragged_batching=1) as hip, host.Plugin(sse, R, F) as s, \
+            host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as off:
         exp = s.score_alignments(host.SW, reads, refs)
         assert np.array_equal(hip.score_alignments(host.SW, reads, refs), exp)
         assert np.array_equal(off.score_alignments(host.SW, reads, refs), exp)
@@ -87,8 +88,10 @@ def test_uniform_batch_is_one_launch():
     reads, refs = synth.make_pairs(n, R, F, seed=48, n_run_frac=0.0, short_frac=0.0)
     exp = cpu_ref.score(host.SW, reads, refs, threads=8)
     eng = hipkernel.Engine(R, F)
+    assert eng.describe()["ragged_batching"] == 0          # off unless asked for
+    eng.set_ragged_batching(1)
     got = eng.score_host(host.SW, reads, refs, threads=2)
-    assert eng.describe()["ragged_launches"] == 0          # default mode: the sample says nothing to skip
+    assert eng.describe()["ragged_launches"] == 0          # mode 1: the sample says nothing to skip
     assert np.array_equal(got, exp)
     eng.set_ragged_batching(2)
     got = eng.score_host(host.SW, reads, refs, threads=2)

@@ -285,8 +285,10 @@ public:
         sse_policy_ = policy == 1;
     }
     // Length-sorted batching of Smith-Waterman score calls that arrive as host pointers:
-    // 0 = never (every pair is swept at read_length x ref_length), 1 = when a sample of the call's
-    // pairs says it would skip a third of the cells (default), 2 = always
+    // 0 = never (every pair is swept at read_length x ref_length; default -- the host's pass over every
+    // sequence tail costs more wall time than the skipped cells save while the host gather is the limit,
+    // profiles/r01_host_path.txt), 1 = when a sample of the call's pairs says it would skip a third of
+    // the cells, 2 = always
     void set_ragged_batching(int mode) {
         if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
         ragged_ = mode;
@@ -522,6 +524,7 @@ public:
         long long chunk = per_pair ? (long long)(score_chunk_bytes_ / per_pair) : n;
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
+        reset_pipeline();
         ensure_staging(chunk);
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
@@ -626,7 +629,7 @@ public:
         // the latency-bound traceback kernel at full occupancy), capped at 24 GiB and half the free HBM.
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
-        const size_t have = trace_pairs_ > 0 ? (size_t)(trace_pairs_ / 2) * bytes_per_pp : 0;
+        const size_t have = trace_bytes_;
         const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
         long long chunk = (long long)(cap / bytes_per_pp) * 2;
         chunk = std::max(ppb, chunk / ppb * ppb);
@@ -735,6 +738,7 @@ public:
         long long chunk = per_pair ? (long long)(align_chunk_bytes_ / per_pair) : n;
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
+        reset_pipeline();
         ensure_staging(chunk);
         ensure_align_staging(chunk);
         if (threads < 1) threads = 1;
@@ -889,12 +893,28 @@ private:
     }
 
 
+    // A call that threw in the middle of the pipeline (a HIP error, `too many length groups`) leaves chunks
+    // pending in the slots; draining them into the NEXT caller's arrays would write at the old offsets.  Every
+    // host-pointer call starts from idle streams and empty slots.
+    void reset_pipeline() {
+        bool stale = false;
+        for (int s = 0; s < kSlots; ++s) stale = stale || slot_pending_[s] != 0;
+        if (!stale) return;
+        for (int s = 0; s < kSlots; ++s) {
+            (void)hipStreamSynchronize(streams_[s]);
+            slot_pending_[s] = 0;
+            slot_begin_[s] = 0;
+            slot_ragged_[s] = false;
+        }
+    }
+
     void release_trace_scratch() {
         if (d_ptr_) (void)hipFree(d_ptr_);
         if (d_ends_) (void)hipFree(d_ends_);
         d_ptr_ = nullptr;
         d_ends_ = nullptr;
         trace_pairs_ = 0;
+        trace_bytes_ = 0;
         for (int s = 0; s < kSlots; ++s) {
             if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
             if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
@@ -908,18 +928,29 @@ private:
         align_staged_pairs_ = 0;
     }
 
+    // The pointer stream's bytes per pair-of-pairs depend on the fill kernel the call selects (tagged /
+    // untagged, 4- or 8-step blocks, one or two code words): capacity is tracked in BYTES, so a call with a
+    // wider stream than the one that sized the scratch reallocates instead of writing past it.
     void ensure_trace_scratch(long long pairs, size_t bytes_per_pp, hipStream_t stream) {
-        if (pairs <= trace_pairs_) return;
-        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // nothing may still read the old scratch
-        if (d_ptr_) (void)hipFree(d_ptr_);
-        if (d_ends_) (void)hipFree(d_ends_);
-        d_ptr_ = nullptr;
-        d_ends_ = nullptr;
         const long long ppw = plan_.pairs_per_wave;
         const long long waves = (pairs + ppw - 1) / ppw;
-        hip_check(hipMalloc((void **)&d_ptr_, (size_t)(waves * (ppw / 2)) * bytes_per_pp), "hipMalloc(pointer scratch)");
-        hip_check(hipMalloc((void **)&d_ends_, sizeof(EndCell) * (size_t)(waves * ppw)), "hipMalloc(end cells)");
-        trace_pairs_ = pairs;
+        const size_t need = (size_t)(waves * (ppw / 2)) * bytes_per_pp;
+        if (need <= trace_bytes_ && pairs <= trace_pairs_) return;
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // nothing may still read the old scratch
+        if (need > trace_bytes_) {
+            if (d_ptr_) (void)hipFree(d_ptr_);
+            d_ptr_ = nullptr;
+            trace_bytes_ = 0;
+            hip_check(hipMalloc((void **)&d_ptr_, need), "hipMalloc(pointer scratch)");
+            trace_bytes_ = need;
+        }
+        if (pairs > trace_pairs_) {
+            if (d_ends_) (void)hipFree(d_ends_);
+            d_ends_ = nullptr;
+            trace_pairs_ = 0;
+            hip_check(hipMalloc((void **)&d_ends_, sizeof(EndCell) * (size_t)(waves * ppw)), "hipMalloc(end cells)");
+            trace_pairs_ = pairs;
+        }
     }
 
     void ensure_align_staging(long long pairs) {
@@ -1217,7 +1248,7 @@ private:
     bool sse_policy_ = false;
     int band_width_ = 0;
     int score_width_ = 0;
-    int ragged_ = 1, force_g_ = 0, force_k_ = 0;
+    int ragged_ = 0, force_g_ = 0, force_k_ = 0;
     size_t score_chunk_bytes_ = 48u << 20;                   // staging chunk of score_host (VALIGN_HIP_CHUNK_BYTES)
     size_t align_chunk_bytes_ = 128u << 20;                  // staging chunk of align_host, inputs + results (VALIGN_HIP_ALIGN_CHUNK_BYTES)
     long long ragged_min_ = 2048;                             // pairs a length bin needs for its own launch
@@ -1249,6 +1280,7 @@ private:
     unsigned *d_ptr_ = nullptr;
     EndCell *d_ends_ = nullptr;
     long long trace_pairs_ = 0, align_staged_pairs_ = 0;
+    size_t trace_bytes_ = 0;            // capacity of d_ptr_
     uint8_t *h_rows_[kSlots] = {}, *d_rows_[kSlots] = {};
     short *h_idx_[kSlots] = {}, *d_idx_[kSlots] = {};
     hipEvent_t in_done_[kSlots] = {}, kernels_done_[kSlots] = {};   // align_host: H2D / kernels of the slot's chunk finished

@@ -72,7 +72,7 @@ public:
             engine_->set_traceback_policy(opt_param("traceback_policy", 0));
             engine_->set_band_width(opt_param("band_width", 0));
             engine_->set_score_width(opt_param("score_width", 0));
-            engine_->set_ragged_batching(opt_param("ragged_batching", 1));
+            engine_->set_ragged_batching(opt_param("ragged_batching", 0));
             // hip_devices = N: the pairs of every call are split into N contiguous shards, one device each
             // (hip_device, hip_device + 1, ... modulo the visible devices), each shard on its own host
             // thread with its own streams and staging.  Results land in the caller's host arrays, so no
@@ -86,7 +86,7 @@ public:
                 more_.back()->set_traceback_policy(opt_param("traceback_policy", 0));
                 more_.back()->set_band_width(opt_param("band_width", 0));
                 more_.back()->set_score_width(opt_param("score_width", 0));
-                more_.back()->set_ragged_batching(opt_param("ragged_batching", 1));
+                more_.back()->set_ragged_batching(opt_param("ragged_batching", 0));
             }
             if (opt_param("host_malloc_tuning", 0) == 1) {
                 // compute_alignments must hand out 2n operator new[] blocks (the caller delete[]s them,
@@ -122,8 +122,7 @@ public:
             });
             log_line(0, "HIPKernel score done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
-            log_line(3, e.what());
-            throw;
+            rethrow_for_host(e.what());
         }
     }
 
@@ -139,12 +138,21 @@ public:
             });
             log_line(0, "HIPKernel align done, host phases " + engine_->host_phases());
         } catch (const std::exception &e) {
-            log_line(3, e.what());
-            throw;
+            rethrow_for_host(e.what());
         }
     }
 
 private:
+    // Errors leave the virtuals the way the reference's kernels raise theirs: logged at level 3, then thrown
+    // as `const char *` (DefaultKernel.h:79-81) -- reference-style hosts catch nothing else, a std::exception
+    // crossing the plugin boundary would end in std::terminate.
+    [[noreturn]] void rethrow_for_host(const char *what) {
+        log_line(3, what);
+        static thread_local std::string thrown;
+        thrown = what;
+        throw thrown.c_str();
+    }
+
     // fn(engine, first pair, pairs, host threads) once per device shard, concurrently; the first error wins
     template <typename Fn>
     void sharded(int n, int threads, Fn fn) {
