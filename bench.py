@@ -8,21 +8,41 @@ configs[1]), inputs already resident in HBM, launched through libHIPKernel.so's 
 rank scores its own 1M-pair shard and the per-shard scores are all-gathered (configs[3]);
 scaling is weak.  GCUPS = pairs * R * F / seconds / 1e9 over all ranks.
 
+`python bench.py --gpus N` from a plain shell starts its own ranks: the parent -- before it
+touches the GPU in any way -- runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child process, relays rank 0's JSON line and exits with the child's code.  Launched by
+torch.distributed.run directly (RANK / WORLD_SIZE in the environment) it is simply one rank.
+
+`--workload long` is BASELINE.json configs[4] per GPU: 32,768 pairs of 10 kbp x 10 kbp, banded
+Smith-Waterman (512 diagonals), int32 cells.
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline ....... HBM roofline of the dominant kernel from ALGORITHMIC bytes
                    (R + F + 2 per pair) / average launch duration
                    measured with events on the launch stream.
   cpu_baseline ... the oracle (this repo's C port of the reference Default kernel, with the
                    same affine extension) timed on the host cores on a bounded sample.
+  half_float ..... the same batch through the half-float-cell kernel (identical scores, checked on
+                   the whole batch) -- the fast path the plugin takes by itself; `value` is the
+                   int16-cell kernel BASELINE.json names.
+  multi_gpu ...... N > 1: ranks seen after the RCCL all-gather, checksum of the gathered vector
+                   against the sum of the ranks' own checksums, and the same K steps without
+                   the all-gather.
+  abi ............ PCIe-inclusive figures THROUGH the plugin ABI (spawn_alignment_kernel, scattered
+                   host pointers): score_alignments and compute_alignments(SW) on the full batch,
+                   and the reference host's own protocol (100 back-to-back calls, src/impl/main.cpp
+                   :268-292) on BASELINE configs[0].  Never part of `value`.
   linear_gap ..... the same batch in the reference's own linear-gap model (the bit-exact
                    path), and the reference's compiled CPU kernels timed beside it when
-                   oracle/_ref travelled with the repo: Default (OpenMP, all threads), AVX2
-                   (one thread, as it runs on Linux) and AVX2 sharded over processes (all cores,
-                   as it was meant to run).
+                   oracle/_ref travelled with the repo.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,80 +50,147 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
-from versalignlib_amd import build, hipkernel, shard
-
 R, F = 150, 500
 PAIRS_PER_GPU = 1 << 20
+LONG_R, LONG_F, LONG_PAIRS_PER_GPU, LONG_BAND = 10000, 10000, 32768, 512
 AFFINE = dict(open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
 HBM_PEAK_GBPS = 8000.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r01_pmc_final.json")
+PMC_PROFILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_final.json")))
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` from a plain shell (no GPU call may precede this)
+# ---------------------------------------------------------------------------------------------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start one rank per GPU as CHILD processes (never an exec: a process that has initialised the GPU
+    must not be replaced, and this parent has not touched it), relay rank 0's JSON line, return the
+    children's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["VALIGN_BENCH_LAUNCHED"] = "1"
+    port = int(env.get("MASTER_PORT", 0)) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)        # anything else a rank printed
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------
+
+def source_hash():
+    """sha256 over the kernel sources: PMC profiles are only quoted for the sources they were taken from."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "versalignlib_amd", "csrc", "*"))):
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(kernel_key, pairs):
+    """Counters of `kernel_key` from the newest committed PMC profile that was taken from EXACTLY these
+    kernel sources at this batch size (tools/pmc_passes.sh + tools/pmc_summary.py stamp `csrc_sha16`);
+    None otherwise -- stale counters are not quoted."""
+    want = source_hash()
+    for path in reversed(PMC_PROFILES):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            if prof.get("csrc_sha16") != want or int(prof["pairs"]) != int(pairs):
+                continue
+            return prof["kernels"][kernel_key], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
 
 
 def measured_traffic(kernel_key, pairs):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE in separate runs, in KB; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the profile is
-    absent or was taken at another batch size."""
+    (FETCH_SIZE and WRITE_SIZE in separate runs, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for wide coalesced reads on gfx950)."""
+    k, _ = pmc_profile(kernel_key, pairs)
+    if k is None:
+        return None
     try:
-        with open(PMC_PROFILE) as f:
-            prof = json.load(f)
-        k = prof["kernels"][kernel_key]
-        if int(prof["pairs"]) != int(pairs):
-            return None
         return float(k["FETCH_SIZE"]) * 1024.0 * 2.0 + float(k["WRITE_SIZE"]) * 1024.0
-    except (OSError, KeyError, ValueError, TypeError):
+    except (KeyError, ValueError, TypeError):
         return None
 
 
 def measured_valu_issue(kernel_key, pairs):
     """The resource that does bind this kernel: share of all SIMD cycles spent issuing VALU
-    instructions, from the same committed PMC passes.  Packed-int16 ops issue one wave64
-    instruction per 4 cycles per SIMD (profiles/r01_valu_rate_microbench.txt); 256 CUs x 4 SIMDs;
-    GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    instructions.  The packed 16-bit ops issue one wave64 instruction per 4 cycles per SIMD
+    (profiles/r02_valu_rate_microbench.txt); 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    k, path = pmc_profile(kernel_key, pairs)
+    if k is None:
+        return None
     try:
-        with open(PMC_PROFILE) as f:
-            prof = json.load(f)
-        k = prof["kernels"][kernel_key]
-        if int(prof["pairs"]) != int(pairs):
-            return None
         issue = float(k["SQ_INSTS_VALU"]) * 4.0 / 1024.0
         cycles = float(k["GRBM_GUI_ACTIVE"]) / 8.0
         return {"bound": "valu-issue", "wave_instructions": float(k["SQ_INSTS_VALU"]),
                 "issue_cycles_per_simd": round(issue), "kernel_cycles": round(cycles),
-                "frac": round(issue / cycles, 4), "source": "profiles/r01_pmc_final.json"}
-    except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
+                "frac": round(issue / cycles, 4), "source": "committed profile " + path}
+    except (KeyError, ValueError, TypeError, ZeroDivisionError):
         return None
 
 
-def synth_on_device(n, device, seed):
+def synth_on_device(n, device, seed, R=R, F=F):
     """SURVEY.md 8(d) batch, generated on the GPU: uniform ACGT refs; reads = ref window
     with 15% substitutions; 1% of pairs carry an N run, 1% are short and NUL padded."""
+    import torch
     g = torch.Generator(device=device).manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    refs = lut[torch.randint(0, 4, (n, F), device=device, generator=g)]
-    off = torch.randint(0, F - R + 1, (n, 1), device=device, generator=g)
+    reads = torch.empty((n, R), dtype=torch.uint8, device=device)
+    refs = torch.empty((n, F), dtype=torch.uint8, device=device)
+    step = max(1, min(n, (64 << 20) // max(R, F)))          # bounded temporaries for the long shapes
     col = torch.arange(R, device=device)[None, :]
-    reads = torch.gather(refs, 1, off + col)
-    sub = torch.rand((n, R), device=device, generator=g) < 0.15
-    reads = torch.where(sub, lut[torch.randint(0, 4, (n, R), device=device, generator=g)], reads)
-    pick = torch.rand((n, 1), device=device, generator=g)
-    start = torch.randint(0, R - 5, (n, 1), device=device, generator=g)
-    run = torch.randint(1, 6, (n, 1), device=device, generator=g)
-    n_run = (pick < 0.01) & (col >= start) & (col < start + run)
-    reads = torch.where(n_run, torch.full_like(reads, ord("N")), reads)
-    keep_r = torch.randint(0, R + 1, (n, 1), device=device, generator=g)
-    keep_f = torch.randint(0, F + 1, (n, 1), device=device, generator=g)
-    short = (pick >= 0.01) & (pick < 0.02)
-    reads = torch.where(short & (col >= keep_r), torch.zeros_like(reads), reads)
     fcol = torch.arange(F, device=device)[None, :]
-    refs = torch.where(short & (fcol >= keep_f), torch.zeros_like(refs), refs)
-    return reads.contiguous(), refs.contiguous()
+    for lo in range(0, n, step):
+        m = min(step, n - lo)
+        rf = lut[torch.randint(0, 4, (m, F), device=device, generator=g)]
+        off = torch.randint(0, F - R + 1, (m, 1), device=device, generator=g)
+        rd = torch.gather(rf, 1, off + col)
+        sub = torch.rand((m, R), device=device, generator=g) < 0.15
+        rd = torch.where(sub, lut[torch.randint(0, 4, (m, R), device=device, generator=g)], rd)
+        pick = torch.rand((m, 1), device=device, generator=g)
+        start = torch.randint(0, R - 5, (m, 1), device=device, generator=g)
+        run = torch.randint(1, 6, (m, 1), device=device, generator=g)
+        n_run = (pick < 0.01) & (col >= start) & (col < start + run)
+        rd = torch.where(n_run, torch.full_like(rd, ord("N")), rd)
+        keep_r = torch.randint(0, R + 1, (m, 1), device=device, generator=g)
+        keep_f = torch.randint(0, F + 1, (m, 1), device=device, generator=g)
+        short = (pick >= 0.01) & (pick < 0.02)
+        reads[lo:lo + m] = torch.where(short & (col >= keep_r), torch.zeros_like(rd), rd)
+        refs[lo:lo + m] = torch.where(short & (fcol >= keep_f), torch.zeros_like(rf), rf)
+    return reads, refs
 
 
 def timed_steps(fn, steps, warmup, world):
+    import torch
+    import torch.distributed as dist
     for _ in range(warmup):
         fn()
     if world > 1:
@@ -126,6 +213,7 @@ def timed_steps(fn, steps, warmup, world):
 
 def kernel_launch_ms(eng, opt, reads, refs, out, reps):
     """Average duration of one kernel launch, events on the stream the kernel runs on."""
+    import torch
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()
@@ -135,29 +223,43 @@ def kernel_launch_ms(eng, opt, reads, refs, out, reps):
     return sum(a.elapsed_time(b) for a, b in ev) / reps
 
 
-def cpu_baseline(reads, refs, affine):
+def host_cores():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    return cores
+
+
+def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
     """Oracle on the host cores over a bounded sample of the same batch (rank 0, N == 1)."""
     from oracle import cpu_ref
     cpu_ref.build()
-    cores = min(cpu_ref.max_threads(), os.cpu_count() or 1)
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
+    cores = min(cpu_ref.max_threads(), host_cores())
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, **(AFFINE if affine else {}))
-    probe = 512 * cores
+
+    def run(h_reads, h_refs):
+        if band:
+            return cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=cores)
+        return cpu_ref.score(0, h_reads, h_refs, sc, threads=cores, affine=affine)
+
+    probe = max(1, (512 * cores * 75000) // (R * F)) if not band else cores
+    probe = min(probe, int(reads.shape[0]))
     h_reads, h_refs = reads[:probe].cpu().numpy(), refs[:probe].cpu().numpy()
     t0 = time.perf_counter()
-    cpu_ref.score(0, h_reads, h_refs, sc, threads=cores, affine=affine)
+    run(h_reads, h_refs)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
-    sample = int(min(reads.shape[0], max(probe, rate * 12.0)))          # ~12 s of CPU work
+    sample = int(min(reads.shape[0], max(probe, rate * seconds)))
     h_reads, h_refs = reads[:sample].cpu().numpy(), refs[:sample].cpu().numpy()
     t0 = time.perf_counter()
-    cpu_ref.score(0, h_reads, h_refs, sc, threads=cores, affine=affine)
+    run(h_reads, h_refs)
     sec = time.perf_counter() - t0
-    return {"value": round(sample * R * F / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": "first %d pairs of the rank-0 batch, SW %s int16, oracle/cpu_ref.c OpenMP over pairs, %.1f s"
-                      % (sample, "affine-gap" if affine else "linear-gap", sec)}
+    what = "SW %s int16" % ("affine-gap" if affine else "linear-gap") if not band else "SW linear-gap banded (%d diagonals)" % band
+    cells = float(sample) * R * F
+    return {"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "first %d pairs of the rank-0 batch, %s, oracle/cpu_ref.c OpenMP over pairs, %.1f s%s"
+                      % (sample, what, sec, " (full-matrix cells counted, as for the GPU)" if band else "")}
 
 
 def reference_cpu_kernels(reads, refs):
@@ -165,11 +267,7 @@ def reference_cpu_kernels(reads, refs):
     from versalignlib_amd import host
     out = {}
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     for name, threads, sample in (("Default", cores, 4096 * max(1, cores // 4)), ("AVX", 1, 8192)):
         path = os.path.join(ref_dir, "lib%sKernel.so" % name)
         if not os.path.exists(path):
@@ -197,7 +295,6 @@ def reference_avx_sharded(reads, refs, procs, pairs_per_proc=32768):
     running the compiled libAVXKernel.so on one thread through the plugin protocol
     (tools/ref_shard_worker.py: ctypes only, no torch, no GPU).  Children start together; the
     slowest one's time counts."""
-    import subprocess
     import tempfile
     import numpy as np
     from versalignlib_amd import build as b
@@ -234,37 +331,152 @@ def reference_avx_sharded(reads, refs, procs, pairs_per_proc=32768):
                                            % (sample, procs, slowest)}
 
 
-def main():
+def abi_leg(reads, refs, threads, devices=1):
+    """PCIe-inclusive figures through the plugin ABI, exactly as a versalignLib host drives a backend:
+    dlopen + set_parameters + set_logger + spawn_alignment_kernel, then the two virtuals on scattered
+    heap blocks (pad(), src/util/versalignUtil.cpp:24-31).  Affine scoring as in `value`.  Warm: the first
+    call of each kind sizes the pinned staging and is not counted."""
+    import numpy as np
+    from versalignlib_amd import build, host, synth
+    n = int(reads.shape[0])
+    h_reads, h_refs = reads.cpu().numpy(), refs.cpu().numpy()
+    keys = dict(score_gap_open_read=AFFINE["open_read"], score_gap_extend_read=AFFINE["ext_read"],
+                score_gap_open_ref=AFFINE["open_ref"], score_gap_extend_ref=AFFINE["ext_ref"])
+    out = {"threads": threads, "pairs": n, "note": "through spawn_alignment_kernel with one heap block per sequence; "
+                                                    "PCIe and host gather/scatter included; never part of `value`"}
+    if devices > 1:
+        keys["hip_devices"] = devices
+        out["hip_devices"] = devices
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
+        k.score_alignments(0, h_reads[:65536], h_refs[:65536], scattered=True)
+        k.score_alignments(0, h_reads, h_refs, scattered=True)
+        secs = sorted(k.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(3))
+        out["score_alignments_sw"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1)}
+        # compute_alignments(SW): 2n operator new[] rows per call (include/AlignmentKernel.h:20-23).
+        # "fresh": rows of earlier calls are still alive, as in the reference's timing loop, which leaks them
+        # (main.cpp:280-285) -- every call gets memory the process has never touched.  "recycled": the host
+        # destroyed the previous call's Alignment array first (what a host that consumes its results does).
+        total, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=False)
+        fresh = min(per_call[1:])
+        phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
+        out["compute_alignments_sw"] = {"ms_fresh_rows": round(fresh * 1e3, 2), "gcups_fresh_rows": round(n * R * F / fresh / 1e9, 1),
+                                        "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
+        total, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=True)
+        recycled = min(per_call[1:])
+        out["compute_alignments_sw"].update({"ms_recycled_rows": round(recycled * 1e3, 2),
+                                             "gcups_recycled_rows": round(n * R * F / recycled / 1e9, 1)})
+    # the reference host's own protocol on BASELINE configs[0]: 1,000 pairs of 64 x 128, linear gaps,
+    # 100 back-to-back compute_alignments(SW) calls, microseconds per call (main.cpp:66-69, 268-292)
+    r1, f1 = synth.make_pairs(1000, 64, 128, seed=1)
+    with host.Plugin(build.HIP_PLUGIN, 64, 128, num_threads=threads) as k:
+        k.time_calls(0, r1, f1, reps=5, align=True)
+        total, _ = k.time_calls(0, r1, f1, reps=100, align=True)
+        total_s, _ = k.time_calls(0, r1, f1, reps=100, align=False)
+        total_nw, _ = k.time_calls(1, r1, f1, reps=100, align=False)
+        out["reference_protocol_config0"] = {"pairs": 1000, "shape": "64x128", "calls": 100,
+                                             "compute_alignments_sw_us_per_call": round(total / 100 * 1e6, 1),
+                                             "score_alignments_sw_us_per_call": round(total_s / 100 * 1e6, 1),
+                                             "score_alignments_nw_us_per_call": round(total_nw / 100 * 1e6, 1)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher self-test (CPU, gloo): no alignment is computed -- it exists so that the path
+# `python bench.py --gpus N` -> child ranks -> all-gather -> one JSON line can be tested without a GPU
+# ---------------------------------------------------------------------------------------------
+
+def selftest_rank(args, world, rank):
+    import torch
+    import torch.distributed as dist
+    from versalignlib_amd import shard
+    dist.init_process_group("gloo")
+    n = args.pairs
+    local = ((torch.arange(n, dtype=torch.int64) * 7 + rank * 1000003) % 30011).to(torch.int16)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = shard.all_gather_scores(local, n_total=n * world)
+    elapsed = time.perf_counter() - t0
+    mine = torch.tensor([int(local.to(torch.int64).sum())], dtype=torch.int64)
+    dist.all_reduce(mine)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no alignment computed)", "value": 0.0, "unit": "none",
+                          "n_gpus": world, "steps": args.steps, "warmup": 0, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "data": "launcher-selftest", "backend": "gloo",
+                          "multi_gpu": {"n_ranks_seen": dist.get_world_size(), "gathered_pairs": int(full.numel()),
+                                        "gather_checksum": int(full.to(torch.int64).sum()),
+                                        "sum_of_rank_checksums": int(mine.item()),
+                                        "checksum_ok": int(full.to(torch.int64).sum()) == int(mine.item())}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU (default: config size)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    args = ap.parse_args()
+    ap.add_argument("--workload", choices=("short", "long"), default="short",
+                    help="short: BASELINE configs[1]/[3] (150x500 SW affine, default); long: configs[4] per GPU "
+                         "(10 kbp x 10 kbp banded SW, int32 cells)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's size)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-abi", action="store_true", help="skip the plugin-ABI (PCIe-inclusive) leg")
+    ap.add_argument("--abi-threads", type=int, default=0, help="num_threads of the ABI leg (default: host cores, <= 16)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU/gloo self-test of launcher + all-gather + result relay; computes no alignment")
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
-                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py ..." % (args.gpus, args.gpus))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, argv)          # nothing above touched the GPU
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.selftest_launcher:
+        if not args.pairs:
+            args.pairs = 1001
+        selftest_rank(args, world, rank)
+        return 0
+
+    import torch
+    import torch.distributed as dist
+    from versalignlib_amd import build, hipkernel, shard
+
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libHIPKernel.so has no CPU path")
+        print("bench.py needs an MI355X: libHIPKernel.so has no CPU path", file=sys.stderr)
+        return 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    gloo = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+        gloo = dist.new_group(backend="gloo")          # host-side waits that keep the GPUs free
 
     if not os.path.exists(build.HIP_PLUGIN):
         build.build_hip()
-    n = args.pairs
-    reads, refs = synth_on_device(n, device, seed=2000 + rank)
+    long_mode = args.workload == "long"
+    RR, FF = (LONG_R, LONG_F) if long_mode else (R, F)
+    n = args.pairs or (LONG_PAIRS_PER_GPU if long_mode else PAIRS_PER_GPU)
+    reads, refs = synth_on_device(n, device, seed=2000 + rank, R=RR, F=FF)
     affine_sc = hipkernel.Scoring.make(2, -1, -3, -3, **AFFINE)
-    eng = hipkernel.Engine(R, F, affine_sc, device=local_rank)
-    eng_lin = hipkernel.Engine(R, F, hipkernel.Scoring.make(), device=local_rank)
+    lin_sc = hipkernel.Scoring.make()
+    if long_mode:
+        eng = hipkernel.Engine(RR, FF, lin_sc, device=local_rank)
+        eng.set_band_width(LONG_BAND)
+        eng.set_score_width(32)
+    else:
+        # `value` is the int16-cell kernel BASELINE.json names; the half-float-cell kernel the engine would
+        # pick by itself for this scoring is reported beside it (half_float)
+        os.environ["VALIGN_HIP_NO_F16"] = "1"
+        eng = hipkernel.Engine(RR, FF, affine_sc, device=local_rank)
+        del os.environ["VALIGN_HIP_NO_F16"]
     local = torch.empty(n, dtype=torch.int16, device=device)
     gathered = [None]
 
@@ -272,88 +484,134 @@ def main():
         eng.score_device(0, reads, refs, local)
         gathered[0] = shard.all_gather_scores(local, n_total=n * world) if world > 1 else local
 
+    def step_no_gather():
+        eng.score_device(0, reads, refs, local)
+
     elapsed = timed_steps(step, args.steps, args.warmup, world)
-    total_cells = float(n) * R * F * world * args.steps
+    total_cells = float(n) * RR * FF * world * args.steps
     value = total_cells / elapsed / 1e9
 
+    multi = None
+    if world > 1:
+        # evidence that the collective did its job: every rank's shard is in the gathered vector
+        mine = local.to(torch.int64).sum().reshape(1)
+        dist.all_reduce(mine)
+        got = gathered[0].to(torch.int64).sum()
+        elapsed_ng = timed_steps(step_no_gather, args.steps, 1, world)
+        multi = {"n_ranks_seen": dist.get_world_size(), "gathered_pairs": int(gathered[0].numel()),
+                 "gather_checksum": int(got.item()), "sum_of_rank_checksums": int(mine.item()),
+                 "checksum_ok": int(got.item()) == int(mine.item()),
+                 "without_all_gather": {"ms_per_step": round(elapsed_ng / args.steps * 1e3, 3),
+                                        "value": round(total_cells / elapsed_ng / 1e9, 1)},
+                 "all_gather_bytes_per_rank": 2 * n, "devices_visible_per_rank": torch.cuda.device_count()}
+
+    rc = 0
     if rank == 0:
         assert gathered[0].numel() == n * world
         k_ms = kernel_launch_ms(eng, 0, reads, refs, local, max(3, min(args.steps, 10)))
-        alg_bytes = float(n) * (R + F + 2)
+        alg_bytes = float(n) * (RR + FF + 2)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         d = eng.describe(0, n)
         cells = d.get("score_cells", "int16")
-        pmc_key = "score_kernel<%d, %d, 0, %d>" % (d["group_lanes"], d["rows_per_lane"], 4 if cells == "f16" else 3)
-        cell_check = None
-        if cells == "f16":
-            # the half-float kernel must reproduce the int16 kernel bit for bit: check it on the whole
-            # batch (outside the timed region) and time the int16 variant beside it
-            os.environ["VALIGN_HIP_NO_F16"] = "1"
-            eng_i16 = hipkernel.Engine(R, F, affine_sc, device=local_rank)
-            del os.environ["VALIGN_HIP_NO_F16"]
-            ref_scores = eng_i16.score_device(0, reads, refs)
-            torch.cuda.synchronize()
-            i16_ms = kernel_launch_ms(eng_i16, 0, reads, refs, ref_scores.clone(), 5)
-            eng.score_device(0, reads, refs, local)
-            torch.cuda.synchronize()
-            cell_check = {"identical_to_int16_kernel": bool(torch.equal(local, ref_scores)),
-                          "int16_kernel_ms": round(i16_ms, 4),
-                          "int16_kernel_gcups": round(n * R * F / (i16_ms * 1e-3) / 1e9, 1),
-                          "note": "cells are integers of magnitude <= 2048: exact in fp16"}
-            eng_i16.close()
+        if long_mode:
+            kernel_name = "score_long_kernel<16,10,SW,shared-gap,int32>"
+            pmc_key = "score_long_kernel<16, 10, 0, true, true>"
+            workload = ("%d pairs/GPU, 10 kbp x 10 kbp, SW linear-gap banded (%d diagonals), int32 cells, inputs resident in HBM%s"
+                        % (n, LONG_BAND, ", RCCL all-gather of scores" if world > 1 else ""))
+            metric = "GCUPS (giga DP cell updates/sec, full-matrix cells) SW banded, 10 kbp x 10 kbp"
+        else:
+            kernel_name = "score_kernel<%d,%d,SW,affine-sym>" % (d["group_lanes"], d["rows_per_lane"])
+            pmc_key = "score_kernel<%d, %d, 0, 3>" % (d["group_lanes"], d["rows_per_lane"])
+            workload = ("%d pairs/GPU, 150 bp x 500 bp, SW affine-gap int16 score (open -5, extend -1), inputs resident in HBM%s"
+                        % (n, ", RCCL all-gather of scores" if world > 1 else ""))
+            metric = "GCUPS (giga DP cell updates/sec) SW affine-gap, 150x500 bp"
         line = {
-            "metric": "GCUPS (giga DP cell updates/sec) SW affine-gap, 150x500 bp",
+            "metric": metric,
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": cells, "data": "synthetic",
-            "config": {"workload": "%d pairs/GPU, 150 bp x 500 bp, SW affine-gap int16 score (open -5, extend -1), "
-                                   "inputs resident in HBM%s" % (n, ", RCCL all-gather of scores" if world > 1 else ""),
-                       "pairs_per_gpu": n, "read_length": R, "ref_length": F, "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
+            "config": {"workload": workload, "pairs_per_gpu": n, "read_length": RR, "ref_length": FF,
+                       "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": measured_traffic(pmc_key, n),
-                         "kernel": "score_kernel<%d,%d,SW,%s>" % (d["group_lanes"], d["rows_per_lane"],
-                                                                  "affine-f16" if d.get("score_cells") == "f16" else "affine"),
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
-                         "kernel_gcups": round(n * R * F / (k_ms * 1e-3) / 1e9, 1),
-                         "note": "integer VALU bound: %.4f B/cell algorithmic, HBM is idle by design" % ((R + F + 2) / (R * F)),
+                         "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
+                         "kernel_gcups": round(n * RR * FF / (k_ms * 1e-3) / 1e9, 1),
+                         "note": "integer VALU bound: %.5f B/cell algorithmic, HBM is idle by design; traffic / valu are quoted "
+                                 "from a committed PMC profile only when it was taken from these exact kernel sources (csrc %s)"
+                                 % ((RR + FF + 2) / (RR * FF), source_hash()),
                          "valu": measured_valu_issue(pmc_key, n)},
         }
-        if cell_check is not None:
-            line["cell_check"] = cell_check
-        lin_ms = kernel_launch_ms(eng_lin, 0, reads, refs, local, 5)
-        line["linear_gap"] = {"kernel_ms": round(lin_ms, 4), "kernel_gcups": round(n * R * F / (lin_ms * 1e-3) / 1e9, 1),
-                              "note": "reference's own gap model (bit-exact path), same batch"}
-        # BASELINE config 3 (NW + traceback) on the same batch, device-resident: extra evidence,
-        # never part of `value`
-        try:
-            AL = R + F
-            rows = torch.empty((n, 2, AL), dtype=torch.uint8, device=device)
-            idx = torch.empty((n, 4), dtype=torch.int16, device=device)
-            line["alignments"] = {}
-            for name, e in (("nw_affine_traceback", eng), ("nw_linear_traceback", eng_lin)):
-                e.align_device(1, reads, refs, rows, idx)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                e.align_device(1, reads, refs, rows, idx)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1)
-                line["alignments"][name] = {"ms": round(ms, 3), "gcups": round(n * R * F / (ms * 1e-3) / 1e9, 1),
-                                            "algorithmic_GBps": round(n * (3 * AL + 8) / (ms * 1e-3) / 1e9, 1)}
-            del rows, idx
-        except hipkernel.HipKernelError as e:
-            line["alignments"] = {"error": str(e)[:200]}
+        if multi is not None:
+            line["multi_gpu"] = multi
+            if not multi["checksum_ok"] or multi["n_ranks_seen"] != world:
+                rc = 3
+        if not long_mode:
+            # the half-float-cell kernel (what the plugin picks by itself for this scoring): identical scores
+            eng_f16 = hipkernel.Engine(RR, FF, affine_sc, device=local_rank)
+            f16_scores = eng_f16.score_device(0, reads, refs)
+            torch.cuda.synchronize()
+            f16_ms = kernel_launch_ms(eng_f16, 0, reads, refs, f16_scores, 5)
+            eng.score_device(0, reads, refs, local)
+            torch.cuda.synchronize()
+            line["half_float"] = {"cells": eng_f16.describe(0, n).get("score_cells"),
+                                  "identical_to_int16_kernel": bool(torch.equal(local, f16_scores)),
+                                  "kernel_ms": round(f16_ms, 4), "kernel_gcups": round(n * RR * FF / (f16_ms * 1e-3) / 1e9, 1),
+                                  "note": "v_pk_maximum3_f16 recurrence on integers of magnitude <= 2048 (exact in fp16); "
+                                          "the engine's own choice for this scoring, bit-identical results"}
+            eng_f16.close()
+            del f16_scores
+            eng_lin = hipkernel.Engine(RR, FF, lin_sc, device=local_rank)
+            lin_ms = kernel_launch_ms(eng_lin, 0, reads, refs, local, 5)
+            line["linear_gap"] = {"kernel_ms": round(lin_ms, 4), "kernel_gcups": round(n * RR * FF / (lin_ms * 1e-3) / 1e9, 1),
+                                  "cells": eng_lin.describe(0, n).get("score_cells"),
+                                  "note": "reference's own gap model (bit-exact path), same batch"}
+            # BASELINE config 3 (NW + traceback) on the same batch, device-resident: extra evidence,
+            # never part of `value`
+            try:
+                AL = RR + FF
+                rows = torch.empty((n, 2, AL), dtype=torch.uint8, device=device)
+                idx = torch.empty((n, 4), dtype=torch.int16, device=device)
+                line["alignments"] = {}
+                for name, e in (("nw_affine_traceback", eng), ("nw_linear_traceback", eng_lin)):
+                    e.align_device(1, reads, refs, rows, idx)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    e.align_device(1, reads, refs, rows, idx)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    line["alignments"][name] = {"ms": round(ms, 3), "gcups": round(n * RR * FF / (ms * 1e-3) / 1e9, 1),
+                                                "algorithmic_GBps": round(n * (3 * AL + 8) / (ms * 1e-3) / 1e9, 1)}
+                del rows, idx
+            except hipkernel.HipKernelError as e:
+                line["alignments"] = {"error": str(e)[:200]}
+            eng_lin.close()
+            if not args.no_abi:
+                try:
+                    threads = args.abi_threads or min(16, host_cores())
+                    line["abi"] = abi_leg(reads, refs, threads)
+                    visible = torch.cuda.device_count()
+                    if world > 1 and visible > 1:
+                        # one host process driving several devices through the plugin key hip_devices, on the
+                        # real devices of this node (the other ranks wait on the host, their GPUs are idle)
+                        line["abi_in_plugin_shards"] = abi_leg(reads, refs, threads, devices=min(world, visible))
+                except Exception as e:
+                    line["abi"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(reads, refs, affine=True)
-            line["linear_gap"]["cpu_port"] = cpu_baseline(reads, refs, affine=False)
-            line["linear_gap"]["cpu_reference"] = reference_cpu_kernels(reads, refs)
+            if long_mode:
+                line["cpu_baseline"] = cpu_baseline(reads, refs, affine=False, R=RR, F=FF, band=LONG_BAND)
+            else:
+                line["cpu_baseline"] = cpu_baseline(reads, refs, affine=True)
+                line["linear_gap"]["cpu_port"] = cpu_baseline(reads, refs, affine=False)
+                line["linear_gap"]["cpu_reference"] = reference_cpu_kernels(reads, refs)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=gloo)
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

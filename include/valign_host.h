@@ -80,6 +80,17 @@ double vh_last_call_seconds(vh_plugin *p);
 int vh_score_scattered(vh_plugin *p, int opt, int n, const uint8_t *reads,
                        const uint8_t *refs, int16_t *scores, double *seconds_out);
 
+/* The reference host's timing protocol (time_kernel, src/impl/main.cpp:268-292): `reps` back-to-back
+ * calls of compute_alignments (align != 0) or score_alignments on the same n pairs, every sequence in
+ * its own heap block (pad()), one timer around the whole loop.  The reference leaks the Alignment rows
+ * of every repetition (main.cpp:280-285); here every repetition gets its own value-initialised
+ * Alignment array and all of them are destroyed after the timer has stopped, so the timed region does
+ * the same work.  seconds_out[0] = the whole loop, seconds_out[1 + r] = repetition r (reps + 1 doubles).
+ * free_between != 0: the rows of one repetition are freed before the next starts, as a host that
+ * consumes its results would (the timed regions still exclude the frees).                             */
+int vh_time_calls(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs, int reps,
+                  int align, int free_between, double *seconds_out);
+
 /* delete_alignment_kernel + dlclose + free.                                          */
 void vh_close(vh_plugin *p);
 

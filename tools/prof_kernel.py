@@ -14,7 +14,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1 << 20)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--modes", default="sw_affine,sw_linear,nw_linear")
+    ap.add_argument("--modes", default="sw_affine16,sw_affine,sw_linear,nw_linear",
+                    help="<alg>_<gap model>; a trailing 16 forces the int16-cell kernels (bench.py's headline)")
     ap.add_argument("--geom", default="0x0")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -23,8 +24,13 @@ def main():
     out = torch.empty(a.pairs, dtype=torch.int16, device=dev)
     for mode in a.modes.split(","):
         alg, gap = mode.split("_")
+        int16_cells = gap.endswith("16")
+        gap = gap[:-2] if int16_cells else gap
         sc = hipkernel.Scoring.make(2, -1, -3, -3, **(bench.AFFINE if gap == "affine" else {}))
+        if int16_cells:
+            os.environ["VALIGN_HIP_NO_F16"] = "1"
         eng = hipkernel.Engine(bench.R, bench.F, sc, group_lanes=G, rows_per_lane=K)
+        os.environ.pop("VALIGN_HIP_NO_F16", None)
         for _ in range(a.reps):
             eng.score_device(0 if alg == "sw" else 1, reads, refs, out)
         torch.cuda.synchronize()

@@ -269,6 +269,47 @@ int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *
 
 double vh_last_call_seconds(vh_plugin *p) { return p ? p->last_call_seconds : 0.0; }
 
+int vh_time_calls(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs, int reps,
+                  int align, int free_between, double *seconds_out) {
+    if (!p || !p->kernel) return fail("kernel not spawned");
+    int R, F;
+    if (!lengths(p, &R, &F)) return fail("read_length / ref_length not set");
+    if (n < 0 || reps < 1 || !seconds_out) return fail("bad argument");
+    std::vector<char *> rp((size_t)n), fp((size_t)n);
+    for (int i = 0; i < n; ++i) {          // one heap block per sequence, as pad() leaves them
+        rp[i] = new char[R > 0 ? R : 1];
+        fp[i] = new char[F > 0 ? F : 1];
+        memcpy(rp[i], reads + (size_t)i * R, (size_t)R);
+        memcpy(fp[i], refs + (size_t)i * F, (size_t)F);
+    }
+    std::vector<short> scores((size_t)n);
+    std::vector<Alignment *> results;
+    double total = 0.0;
+    int rc = 0;
+    for (int r = 0; r < reps && rc == 0; ++r) {
+        Alignment *alns = align ? new Alignment[(size_t)n]() : nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = guarded(align ? "compute_alignments" : "score_alignments", [&] {
+            if (align) p->kernel->compute_alignments(opt, n, rp.data(), fp.data(), alns);
+            else p->kernel->score_alignments(opt, n, rp.data(), fp.data(), scores.data());
+        });
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        seconds_out[1 + r] = sec;
+        total += sec;
+        if (alns) {
+            if (free_between) delete[] alns;          // ~Alignment delete[]s the rows
+            else results.push_back(alns);
+        }
+    }
+    seconds_out[0] = total;
+    for (Alignment *a : results) delete[] a;
+    for (int i = 0; i < n; ++i) {
+        delete[] rp[i];
+        delete[] fp[i];
+    }
+    return rc;
+}
+
 void vh_close(vh_plugin *p) {
     if (!p) return;
     if (p->kernel) {

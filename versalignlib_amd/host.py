@@ -39,6 +39,8 @@ def lib():
         L.vh_score_scattered.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, i16p,
                                          ctypes.POINTER(ctypes.c_double)]
         L.vh_align.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, u8p, i16p, ctypes.c_int]
+        L.vh_time_calls.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_double)]
         L.vh_last_call_seconds.restype = ctypes.c_double
         L.vh_last_call_seconds.argtypes = [vp]
         L.vh_close.restype = None
@@ -149,6 +151,17 @@ class Plugin:
         if rc != 0:
             raise PluginError(_err())
         return rows, idx
+
+    def time_calls(self, opt, reads, refs, reps=100, align=True, free_between=False):
+        """The reference host's timing loop (time_kernel, src/impl/main.cpp:268-292): `reps` back-to-back
+        virtual calls on scattered heap blocks.  -> (seconds of the whole loop, [seconds per call])."""
+        reads, refs = self._inputs(reads, refs)
+        out = (ctypes.c_double * (reps + 1))()
+        rc = lib().vh_time_calls(self._h, opt, reads.shape[0], _u8(reads), _u8(refs), int(reps), 1 if align else 0,
+                                 1 if free_between else 0, out)
+        if rc != 0:
+            raise PluginError(_err())
+        return out[0], list(out[1:])
 
     def last_call_seconds(self):
         """Wall seconds inside the plugin's last compute_alignments call."""
