@@ -241,7 +241,7 @@ def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
 
     def run(h_reads, h_refs):
         if band:
-            return cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=cores)
+            return cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=cores, block_rows=160, col_align=4)   # VALIGN_HIP_BAND_*: the same cells as the GPU
         return cpu_ref.score(0, h_reads, h_refs, sc, threads=cores, affine=affine)
 
     probe = max(1, (512 * cores * 75000) // (R * F)) if not band else cores

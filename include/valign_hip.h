@@ -93,10 +93,18 @@ void valign_hip_engine_destroy(valign_hip_engine *e);
  * N invalid for the NW end cell; src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 532-536).          */
 int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
 
-/* Banded Smith-Waterman scores: rows are processed in strips of 160; a strip only sweeps the
- * columns within diagonals/2 of the (scaled) main diagonal through its rows and every cell
- * outside those rectangles counts as 0.  0 (default) computes every cell; a band wider than the
- * matrix gives the unbanded result.  An extension: the reference has no banding.                 */
+/* Banded Smith-Waterman scores (an extension: the reference has no banding).  Definition, w = diagonals / 2:
+ * the per-cell band is |j - floor(i * ref_length / read_length)| <= w (i, j 0-based read / ref positions).
+ * The library computes AT LEAST that band: the read's rows are taken in blocks of
+ * VALIGN_HIP_BAND_BLOCK_ROWS consecutive rows (the last block ends with the last row), and a block computes
+ * the columns [floor(r_first * F / R) - w, floor(r_last * F / R) + w] of its rows r_first..r_last, the lower
+ * end rounded down to a multiple of VALIGN_HIP_BAND_COL_ALIGN; every other cell counts as 0 and cannot hold
+ * the maximum.  Hence  score(per-cell band w) <= result <= score(all cells),  and the result equals this
+ * block definition exactly (oracle/cpu_ref.c, vref_score_banded_sw, restates it with the two constants as
+ * parameters; block 1 / align 1 is the per-cell band).  0 (default) computes every cell; a band wider than
+ * the matrix gives the unbanded result.                                                                   */
+#define VALIGN_HIP_BAND_BLOCK_ROWS 160
+#define VALIGN_HIP_BAND_COL_ALIGN 4
 int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
 
 /* DP cell width of the score path: 0 (default) = int16 like the reference, switching to int32 cells

@@ -536,53 +536,66 @@ int vref_align_sse(int opt, int n, int R, int F, const uint8_t *reads, const uin
     return n;
 }
 
-/* ---- banded Smith-Waterman score (extension; mirrors the HIP long-read path's "strip band") ----
- * Rows are grouped in blocks of block_rows, aligned to the END of the read (padding rows sit above
- * row 0).  Block b only computes the columns [center(first row) - w, center(last row) + w],
- * center(r) = r * F / R, lower end rounded down to a multiple of 4; every cell outside those
- * rectangles counts as 0.  band_half < 0 computes every cell.                                     */
-static void band_columns(int b, int R, int F, int block_rows, int pad, int w, int *lo, int *hi) {
+/* ---- banded Smith-Waterman score (extension: the reference has no banding) ----
+ * DEFINITION (include/valign_hip.h, "band_width"): the read's rows are taken in blocks of `block_rows`
+ * consecutive rows, the LAST block ending with the last row of the read (so a short first block when
+ * block_rows does not divide R).  A block computes the columns
+ *      [ floor(r_first * F / R) - w ,  floor(r_last * F / R) + w ]        (w = band_width / 2)
+ * of its rows r_first .. r_last, clipped to the matrix, the lower end rounded down to a multiple of
+ * `col_align`; every other cell counts as 0 and cannot hold the maximum.
+ *   block_rows = 1, col_align = 1 ..... the per-cell band |j - floor(i * F / R)| <= w
+ *   block_rows = 160, col_align = 4 ... what libHIPKernel.so computes (VALIGN_HIP_BAND_BLOCK_ROWS /
+ *                                       VALIGN_HIP_BAND_COL_ALIGN): a superset of the per-cell band, so its
+ *                                       score lies between the per-cell-band score and the unbanded one.
+ * band_half < 0 computes every cell.  Cells are int32 here and the result saturates at 32767 (the ABI's
+ * short), like vref_score_wide; inside the int16 range that is the reference's arithmetic.               */
+static void band_columns(int b, int R, int F, int block_rows, int col_align, int pad, int w, int *lo, int *hi) {
     if (w < 0 || R <= 0) { *lo = 0; *hi = F - 1; return; }
     int r_lo = b * block_rows - pad, r_hi = (b + 1) * block_rows - pad - 1;
     if (r_lo < 0) r_lo = 0;
     if (r_hi > R - 1) r_hi = R - 1;
     long long l = (long long)r_lo * F / R - w, h = (long long)r_hi * F / R + w;
-    *lo = (int)(l < 0 ? 0 : l) & ~3;
+    if (l < 0) l = 0;
+    *lo = (int)(l - l % col_align);
     *hi = (int)(h > F - 1 ? F - 1 : h);
 }
 
 int vref_score_banded_sw(int n, int R, int F, const uint8_t *reads, const uint8_t *refs, const vref_scoring *sc,
-                         int block_rows, int band_half, int16_t *scores, int threads) {
+                         int block_rows, int col_align, int band_half, int16_t *scores, int threads) {
     class_init();
     int16_t tab[6][6];
     subst_init(sc, tab);
-    const int16_t gr = (int16_t)sc->gap_read, gf = (int16_t)sc->gap_ref;
+    const int gr = sc->gap_read, gf = sc->gap_ref;
+    if (block_rows < 1) block_rows = 1;
+    if (col_align < 1) col_align = 1;
     const int blocks = R > 0 ? (R + block_rows - 1) / block_rows : 1;
     const int pad = blocks * block_rows - R;
     if (threads < 1) threads = 1;
 #pragma omp parallel num_threads(threads)
     {
-        int16_t *prev = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
-        int16_t *cur = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
+        int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
 #pragma omp for schedule(static)
         for (int p = 0; p < n; ++p) {
             const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
-            memset(prev, 0, sizeof(int16_t) * (size_t)(F + 1));
-            int16_t best = 0;
+            memset(prev, 0, sizeof(int32_t) * (size_t)(F + 1));
+            int32_t best = 0;
             for (int i = 0; i < R; ++i) {
                 int lo, hi;
-                band_columns((i + pad) / block_rows, R, F, block_rows, pad, band_half, &lo, &hi);
-                memset(cur, 0, sizeof(int16_t) * (size_t)(F + 1));
+                band_columns((i + pad) / block_rows, R, F, block_rows, col_align, pad, band_half, &lo, &hi);
+                memset(cur, 0, sizeof(int32_t) * (size_t)(F + 1));
                 const int16_t *srow = tab[g_class[rd[i]]];
                 for (int j = lo; j <= hi; ++j) {
-                    const int16_t diag = (int16_t)(prev[j] + srow[g_class[rf[j]]]);
-                    const int16_t h = max16((int16_t)(prev[j + 1] + gf), max16((int16_t)(cur[j] + gr), max16(diag, 0)));
+                    int32_t h = prev[j] + srow[g_class[rf[j]]];
+                    if (prev[j + 1] + gf > h) h = prev[j + 1] + gf;
+                    if (cur[j] + gr > h) h = cur[j] + gr;
+                    if (h < 0) h = 0;
                     cur[j + 1] = h;
-                    best = max16(best, h);
+                    if (h > best) best = h;
                 }
-                int16_t *t = prev; prev = cur; cur = t;
+                int32_t *t = prev; prev = cur; cur = t;
             }
-            scores[p] = best;
+            scores[p] = (int16_t)(best > 32767 ? 32767 : best);
         }
         free(cur);
         free(prev);

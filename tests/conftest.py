@@ -29,3 +29,11 @@ def ref_kernel(name):
     """Path of a reference kernel compiled by oracle/Makefile, or None when absent."""
     path = os.path.join(ROOT, "oracle", "_ref", "lib%sKernel.so" % name)
     return path if os.path.exists(path) else None
+
+
+def band_constants():
+    """(block_rows, col_align) of libHIPKernel.so's documented band, read from include/valign_hip.h."""
+    import re
+    text = open(os.path.join(ROOT, "include", "valign_hip.h")).read()
+    return (int(re.search(r"#define\s+VALIGN_HIP_BAND_BLOCK_ROWS\s+(\d+)", text).group(1)),
+            int(re.search(r"#define\s+VALIGN_HIP_BAND_COL_ALIGN\s+(\d+)", text).group(1)))

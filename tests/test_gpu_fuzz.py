@@ -34,9 +34,10 @@ def _draw(case):
     kind = pick(8, 0, 3)
     if kind == 1:                                            # symmetric affine
         o, e = -pick(9, 0, 9), -pick(10, 0, 4)
-        affine = (o, e, o, e)
+        affine = (o, max(e, o), o, max(e, o))                # an extension is never dearer than the opening
     elif kind == 2:                                          # four different scores
-        affine = (-pick(9, 0, 9), -pick(10, 0, 4), -pick(11, 0, 9), -pick(12, 0, 4))
+        o_r, e_r, o_f, e_f = -pick(9, 0, 9), -pick(10, 0, 4), -pick(11, 0, 9), -pick(12, 0, 4)
+        affine = (o_r, max(e_r, o_r), o_f, max(e_f, o_f))
     n = pick(13, 1, 400)
     return dict(R=R, F=F, n=n, match=match, mismatch=mismatch, gap_read=gap_read, gap_ref=gap_ref,
                 affine=affine, seed=100 + case, sse=(kind == 3 and pick(14, 0, 1) == 1))

@@ -8,6 +8,8 @@ import pytest
 from oracle import cpu_ref
 from versalignlib_amd import build, host, synth
 
+from conftest import band_constants
+
 pytestmark = pytest.mark.gpu
 
 
@@ -59,30 +61,100 @@ def test_config5_shape_10k_by_10k():
 @pytest.mark.parametrize("R,F,n,seed", [(400, 450, 120, 1), (1000, 1300, 33, 2), (150, 500, 203, 3), (3000, 2800, 10, 4)])
 @pytest.mark.parametrize("band", [16, 64, 512, 100000])
 def test_banded_smith_waterman(R, F, n, seed, band):
-    """band_width: strip-banded SW scores (extension, own oracle); a band wider than the matrix
-    is the unbanded result, i.e. the reference's."""
+    """band_width (extension).  The definition is geometry-free (include/valign_hip.h): AT LEAST the per-cell
+    band |j - floor(i F / R)| <= w, exactly the block band with the two documented constants.  Checked:
+    equality with the oracle's restatement of the block definition; the sandwich
+    per-cell band <= result <= unbanded; and a band wider than the matrix is the reference's result."""
     reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
+    block_rows, col_align = band_constants()
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band) as hip:
         got = hip.score_alignments(0, reads, refs)
         assert '"band_width": %d' % band in hip.drain_log()
         with pytest.raises(host.PluginError, match="Smith-Waterman scores only"):
             hip.score_alignments(1, reads, refs)
-    exp = cpu_ref.score_banded_sw(reads, refs, band, threads=8)
+    exp = cpu_ref.score_banded_sw(reads, refs, band, threads=8, block_rows=block_rows, col_align=col_align)
     assert np.array_equal(got, exp), (np.nonzero(got != exp)[0][:8], got[:8], exp[:8])
+    per_cell = cpu_ref.score_banded_sw(reads, refs, band, threads=8)
+    full = cpu_ref.score(0, reads, refs, threads=8)
+    assert (per_cell <= got).all() and (got <= full).all()
     if band >= 2 * max(R, F):
-        assert np.array_equal(got, cpu_ref.score(0, reads, refs, threads=8))
+        assert np.array_equal(got, full) and np.array_equal(per_cell, full)
+
+
+def test_band_definitions_differ_where_they_should():
+    """The sandwich is not vacuous: on reads with a long insertion the per-cell band, the block band and the
+    full matrix give three different scores for some pairs (CPU restatements only), and the HIP result is the
+    block one."""
+    R, F, n, band = 1200, 1200, 48, 64
+    rng = np.random.default_rng(9)
+    refs = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n, F))
+    reads = refs.copy()
+    for p in range(n):                     # shift the second half of the read by 20..120 bases: the optimum leaves a narrow band
+        shift = int(rng.integers(20, 120))
+        cut = int(rng.integers(300, 700))
+        reads[p, cut + shift:] = refs[p, cut:F - shift]
+        reads[p, cut:cut + shift] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=shift)
+    block_rows, col_align = band_constants()
+    per_cell = cpu_ref.score_banded_sw(reads, refs, band, threads=8)
+    block = cpu_ref.score_banded_sw(reads, refs, band, threads=8, block_rows=block_rows, col_align=col_align)
+    full = cpu_ref.score(0, reads, refs, threads=8)
+    assert (per_cell <= block).all() and (block <= full).all()
+    assert (per_cell < block).any() and (block < full).any()
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band) as hip:
+        assert np.array_equal(hip.score_alignments(0, reads, refs), block)
 
 
 def test_config5_banded_10k():
-    """BASELINE config 5 as stated: 10 kbp x 10 kbp, band of 512 diagonals."""
+    """BASELINE config 5 as stated: 10 kbp x 10 kbp, band of 512 diagonals, int32 cells (score_width = 32) --
+    and the int16 cells the engine would pick by itself for these scores give the same result."""
     R = F = 10000
     n = 24
     reads, refs = synth.make_pairs(n, R, F, seed=56, sub_rate=0.1, indel_rate=0.0, n_run_frac=0.2, short_frac=0.1)
-    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512) as hip:
+    block_rows, col_align = band_constants()
+    exp = cpu_ref.score_banded_sw(reads, refs, 512, threads=8, block_rows=block_rows, col_align=col_align)
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512, score_width=32) as hip:
         got = hip.score_alignments(0, reads, refs)
-    assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, 512, threads=8))
+        assert '"score_cells": "int32"' in hip.drain_log()
+    assert np.array_equal(got, exp)
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512) as hip:
+        assert np.array_equal(hip.score_alignments(0, reads, refs), exp)
+        assert '"score_cells": "int16"' in hip.drain_log()
     full = cpu_ref.score(0, reads[:4], refs[:4], threads=8)
     assert (got[:4] <= full).all()
+    assert (cpu_ref.score_banded_sw(reads[:4], refs[:4], 512, threads=8) <= got[:4]).all()
+
+
+def test_config5_cells_that_need_int32():
+    """10 kbp x 10 kbp with match = 5: cells climb past 32767, int16 would wrap (the reference does, silently).
+    Auto mode must take the int32 cells -- unbanded and banded -- and saturate the ABI's short at 32767."""
+    R = F = 10000
+    n = 6
+    reads, refs = synth.make_pairs(n, R, F, seed=58, sub_rate=0.12, indel_rate=0.0, n_run_frac=0.0, short_frac=0.5)
+    sc = cpu_ref.Scoring.make(5, -4, -6, -6)
+    keys = dict(score_match=5, score_mismatch=-4, score_gap_read=-6, score_gap_ref=-6)
+    block_rows, col_align = band_constants()
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        got = hip.score_alignments(0, reads, refs)
+        assert '"score_cells": "int32"' in hip.drain_log()
+    exp = cpu_ref.score(0, reads, refs, sc, threads=8, wide=True)
+    assert np.array_equal(got, exp)
+    assert (exp == 32767).any() and ((exp > 0) & (exp < 32767)).any()
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512, **keys) as hip:
+        got = hip.score_alignments(0, reads, refs)
+        assert '"score_cells": "int32"' in hip.drain_log()
+    assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, 512, sc, threads=8, block_rows=block_rows, col_align=col_align))
+
+
+def test_config5_unbanded_int32_cells_forced():
+    """The 10 kbp x 10 kbp shape on int32 cells (BASELINE config 5 names int32) against the oracle."""
+    R = F = 10000
+    n = 5
+    reads, refs = synth.make_pairs(n, R, F, seed=57, sub_rate=0.1, indel_rate=0.0, n_run_frac=0.2, short_frac=0.2)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_width=32) as hip:
+        for opt in (0, 1):
+            got = hip.score_alignments(opt, reads, refs)
+            assert np.array_equal(got, cpu_ref.score(opt, reads, refs, threads=8, wide=True)), opt
+        assert '"score_cells": "int32"' in hip.drain_log()
 
 
 @pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 7), (400, 333, 40, 8), (2500, 700, 9, 9)])

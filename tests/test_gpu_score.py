@@ -120,11 +120,10 @@ def test_missing_required_key_throws_like_the_reference():
         host.Plugin(build.HIP_PLUGIN, 10, 10, score_match=None)
 
 
-def test_full_size_properties_config2():
-    """BASELINE config 2 shape at a size the oracle cannot cover in seconds: properties only.
-    (a) the batch is 64 copies of a 4096-pair block -> scores repeat with period 4096;
-    (b) the first block equals the oracle; (c) SW(read, read-as-ref prefix) sanity: identical
-    pairs score 2 * valid bases."""
+def test_full_size_properties_linear_gap():
+    """The BASELINE config 2 shape in the reference's own linear-gap model at a size the oracle cannot
+    cover in seconds: properties only.  The batch is 64 copies of a 4096-pair block -> scores repeat with
+    period 4096, and the first block equals the oracle."""
     import torch
     R, F, blk, reps = 150, 500, 4096, 64
     reads, refs = synth.make_pairs(blk, R, F, seed=51)
@@ -135,6 +134,31 @@ def test_full_size_properties_config2():
         got = eng.score_device(opt, d_reads, d_refs).cpu().numpy().reshape(reps, blk)
         assert (got == got[0]).all()
         assert np.array_equal(got[0], cpu_ref.score(opt, reads, refs, threads=8))
+    eng.close()
+
+
+@pytest.mark.parametrize("cells", ["f16", "int16"])
+def test_full_size_properties_config2(monkeypatch, cells):
+    """BASELINE config 2 as stated: 1,048,576 pairs of 150 x 500, Smith-Waterman AFFINE (open -5, extend -1),
+    on the kernel the engine picks by itself (half-float cells) and on the int16-cell kernel bench.py headlines.
+    The batch is 256 copies of a 4096-pair block: scores must repeat with that period (checked on the device)
+    and the first block must equal the oracle; NW variant as well."""
+    import torch
+    if cells == "int16":
+        monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+    R, F, blk, reps = 150, 500, 4096, 256
+    reads, refs = synth.make_pairs(blk, R, F, seed=53, indel_rate=0.01)
+    aff = (-5, -1, -5, -1)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
+    assert eng.describe(0, blk * reps)["score_cells"] == cells
+    osc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    d_reads = torch.from_numpy(reads).cuda().repeat(reps, 1).contiguous()
+    d_refs = torch.from_numpy(refs).cuda().repeat(reps, 1).contiguous()
+    assert d_reads.shape[0] == 1 << 20
+    for opt in (0, 1):
+        got = eng.score_device(opt, d_reads, d_refs).view(reps, blk)
+        assert bool((got == got[0:1]).all())
+        assert np.array_equal(got[0].cpu().numpy(), cpu_ref.score(opt, reads, refs, osc, threads=8, affine=True))
     eng.close()
 
 

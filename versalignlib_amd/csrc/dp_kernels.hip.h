@@ -388,6 +388,34 @@ __device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, 
     merge_profile<K>(va, vb, S);
 }
 
+// Profile fetch WITHOUT the merge instruction: the K scores of pair A are loaded straight into the low halves
+// and those of pair B into the high halves of the K packed registers with 16-bit LDS loads that leave the other
+// half of the destination alone (ds_read_u16_d16 / ds_read_u16_d16_hi).  The v_perm_b32 per register that
+// merge_profile needs is one of the ~10 VALU instructions of a cell pair and VALU issue is what binds these kernels;
+// the LDS array has the cycles to spare (2K narrow loads per step instead of K/2..K wide ones, same bytes).
+// The loads are inline asm, so the compiler does not count them: profile_wait() is the s_waitcnt before the first
+// use (its own waits only become more conservative with extra operations in flight: LDS returns in order).
+#ifndef VALIGN_D16_PROFILE
+#define VALIGN_D16_PROFILE 1
+#endif
+constexpr bool kD16Profile = VALIGN_D16_PROFILE != 0;
+
+template <int K>
+__device__ __forceinline__ void profile_load_d16(unsigned addr_a, unsigned addr_b, s16x2 (&S)[K]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        asm volatile("ds_read_u16_d16 %0, %1 offset:%2" : "+v"(S[q]) : "v"(addr_a), "n"(2 * q));
+        asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(S[q]) : "v"(addr_b), "n"(2 * q));
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void profile_wait(s16x2 (&S)[K]) {
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(S[q]));      // every use of S[q] stays behind the wait
+}
+
 // GAPS selects the recurrence: kGapLinear (two gap scores), kGapSym (linear with
 // gap_read == gap_ref: one subtract serves both neighbours), kGapAffine (Gotoh extension).
 constexpr int kGapLinear = 0;
@@ -510,11 +538,18 @@ score_kernel(const ScoreArgs args) {
     // at one wave per SIMD).
     constexpr bool PIPE = true;
     unsigned pa[K / 2], pb[K / 2];
+    s16x2 S0[K], S1[K];          // kD16Profile: the scores of this step and of the next, roles swap every step
     unsigned ca_next = 0, cb_next = 0;
     if (PIPE) {
         const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
-        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
-        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        if (kD16Profile) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) S0[q] = S1[q] = pk(0);
+            profile_load_d16<K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S0);
+        } else {
+            lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+            lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
+        }
         ca_next = *(lds_cu8 *)(code_addr + 2);
         cb_next = *(lds_cu8 *)(code_addr + 3);
     }
@@ -526,7 +561,7 @@ score_kernel(const ScoreArgs args) {
     // (kTrackNone), the second adds every max(left, up) plus its last row (kTrackPair): the "left"s
     // are all cells of the first step, the "up"s all cells of the second but the last row.  K + 1
     // maxima per two steps instead of 2K.
-    auto step = [&](auto masked_tag, auto track_tag) __attribute__((always_inline)) {
+    auto step = [&](auto masked_tag, auto track_tag, s16x2 (&S)[K], s16x2 (&Snext)[K]) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int TRACK = decltype(track_tag)::value;
         const s16x2 diag0 = up0;
@@ -545,11 +580,15 @@ score_kernel(const ScoreArgs args) {
         }
         s16x2 gup0 = pk(0);        // kGapSymF16 (SW): max(h + g, 0) of the row above
         if (LINF16_SW) gup0 = as_pk(from_prev_lane(as_u32(f_last)) & lmask);
-        s16x2 S[K];
         if (PIPE) {
-            merge_profile<K>(pa, pb, S);                                     // step t's scores
-            lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows
-            lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+            if (kD16Profile) {
+                profile_wait<K>(S);                                              // step t's scores have landed
+                profile_load_d16<K>(lane_base + ca_next * geo::kPairStride, lane_base + cb_next * geo::kPairStride, Snext);
+            } else {
+                merge_profile<K>(pa, pb, S);                                     // step t's scores
+                lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows
+                lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
+            }
             ca_next = *(lds_cu8 *)(code_addr + 4);                            // step t+2's slab numbers
             cb_next = *(lds_cu8 *)(code_addr + 5);
         }
@@ -728,15 +767,23 @@ score_kernel(const ScoreArgs args) {
     using all_t = std::integral_constant<int, kTrackAll>;
     using first_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackNone : kTrackAll>;
     using second_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackPair : kTrackAll>;
-    for (; t < fill_end; ++t) step(std::true_type{}, all_t{});
+    // a lone step consumes S0 and fills S1: the scores move back (d16 fetch; only in the short fill / drain phases)
+    auto single = [&](auto masked_tag) __attribute__((always_inline)) {
+        step(masked_tag, all_t{}, S0, S1);
+        if (kD16Profile) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) S0[q] = S1[q];
+        }
+    };
+    for (; t < fill_end; ++t) single(std::true_type{});
     {                                          // two steps per trip: loop-carried registers swap roles
         for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW linear,
-            step(std::false_type{}, first_t{});    // +4 % affine together with the pipelined fetch)
-            step(std::false_type{}, second_t{});
+            step(std::false_type{}, first_t{}, S0, S1);    // +4 % affine together with the pipelined fetch)
+            step(std::false_type{}, second_t{}, S1, S0);
         }
     }
-    for (; t < steady_end; ++t) step(std::false_type{}, all_t{});
-    for (; t < steps; ++t) step(std::true_type{}, all_t{});
+    for (; t < steady_end; ++t) single(std::false_type{});
+    for (; t < steps; ++t) single(std::true_type{});
 
     // ---- result ----
     s16x2 res;

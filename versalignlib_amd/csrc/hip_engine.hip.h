@@ -821,6 +821,13 @@ private:
         const bool gaps_ok = sc_.affine ? (sc_.open_read <= 0 && sc_.ext_read <= 0 && sc_.open_ref <= 0 && sc_.ext_ref <= 0)
                                         : (sc_.gap_read <= 0 && sc_.gap_ref <= 0);
         if (!gaps_ok) throw std::runtime_error("positive gap scores are not supported by the HIP kernels");
+        // Affine model: a maximal run of k gap bases costs open + (k - 1) * extend.  The Gotoh recurrence only
+        // computes that while extending is not dearer than opening -- otherwise it re-opens instead (H of the
+        // previous cell may itself end in a gap), which exhaustive enumeration exposes
+        // (tests/golden/make_affine_golden.py).  Refused rather than silently computing another model.
+        if (sc_.affine && (sc_.ext_read < sc_.open_read || sc_.ext_ref < sc_.open_ref))
+            throw std::runtime_error("affine gap scores need extend >= open in each direction (an extension dearer "
+                                     "than the opening is not an affine model)");
     }
 
     LaunchPlan choose_plan(int R, int F, int force_g, int force_k) const {

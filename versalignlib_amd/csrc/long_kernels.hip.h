@@ -20,6 +20,7 @@
 #pragma once
 
 #include "dp_kernels.hip.h"
+#include "valign_hip.h"
 
 namespace valign {
 
@@ -80,6 +81,8 @@ struct LongLds {
 template <int G, int K>
 __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows, int band_half, int &c_lo, int &c_hi) {
     constexpr int rows = G * K;
+    static_assert(rows == VALIGN_HIP_BAND_BLOCK_ROWS, "the band is defined on blocks of this many rows (include/valign_hip.h)");
+    static_assert(VALIGN_HIP_BAND_COL_ALIGN == 4, "c_lo is rounded down to a multiple of 4 below");
     if (band_half < 0 || R <= 0) {
         c_lo = 0;
         c_hi = F - 1;
