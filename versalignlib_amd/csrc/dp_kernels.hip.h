@@ -388,15 +388,18 @@ __device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, 
     merge_profile<K>(va, vb, S);
 }
 
-// Profile fetch WITHOUT the merge instruction: the K scores of pair A are loaded straight into the low halves
-// and those of pair B into the high halves of the K packed registers with 16-bit LDS loads that leave the other
-// half of the destination alone (ds_read_u16_d16 / ds_read_u16_d16_hi).  The v_perm_b32 per register that
-// merge_profile needs is one of the ~10 VALU instructions of a cell pair and VALU issue is what binds these kernels;
-// the LDS array has the cycles to spare (2K narrow loads per step instead of K/2..K wide ones, same bytes).
+// Profile fetch WITHOUT the merge instruction (tuning switch, OFF: measured slower, see below): the K scores of
+// pair A are loaded straight into the low halves and those of pair B into the high halves of the K packed registers
+// with 16-bit LDS loads that leave the other half of the destination alone (ds_read_u16_d16 / _d16_hi).  That removes
+// the v_perm_b32 per register of merge_profile -- the hot loop drops from 217 to 197 VALU instructions per step pair
+// (int16 affine) and from 187 to 167 (half floats) -- but 2K narrow loads per step instead of ~K/2 wide ones cost
+// more than the 10 % VALU they save: 1 M pairs 150 x 500, MI355X, round 2: int16 affine 13.10 -> 13.54 ms, half-float
+// affine 11.47 -> 12.14 ms, linear 7.19 -> 8.66 ms (gpurun_out r02_bench_a vs r02_bench_b).  Every LDS return
+// writes a full wave of VGPRs whatever its width, and that write traffic competes with the VALU.
 // The loads are inline asm, so the compiler does not count them: profile_wait() is the s_waitcnt before the first
 // use (its own waits only become more conservative with extra operations in flight: LDS returns in order).
 #ifndef VALIGN_D16_PROFILE
-#define VALIGN_D16_PROFILE 1
+#define VALIGN_D16_PROFILE 0
 #endif
 constexpr bool kD16Profile = VALIGN_D16_PROFILE != 0;
 
@@ -771,6 +774,7 @@ score_kernel(const ScoreArgs args) {
     auto single = [&](auto masked_tag) __attribute__((always_inline)) {
         step(masked_tag, all_t{}, S0, S1);
         if (kD16Profile) {
+            profile_wait<K>(S1);                   // the copy reads registers the loads of this step are still filling
 #pragma unroll
             for (int q = 0; q < K; ++q) S0[q] = S1[q];
         }
