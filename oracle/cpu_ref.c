@@ -325,6 +325,57 @@ int vref_score_affine(int opt, int n, int R, int F, const uint8_t *reads, const 
 }
 
 
+/* The same recurrence on int32 cells (extension of the extension): for (shape, scoring) whose cells would leave
+ * int16 -- long reads.  "Minus infinity" is far below any reachable cell; the result saturates at 32767, the
+ * largest score the ABI's short can carry.  Inside the int16 range it equals vref_score_affine.               */
+int vref_score_affine_wide(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                           const vref_scoring *sc, int16_t *scores, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int oR = sc->open_read, eR = sc->ext_read, oF = sc->open_ref, eF = sc->ext_ref;
+    const int alg = opt & 0xF;
+    const int32_t ninf = -(1 << 29);
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int32_t *H = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *Fv = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            for (int j = 0; j <= F; ++j) { H[j] = 0; Fv[j] = ninf; }
+            int32_t best = 0;
+            for (int i = 0; i < R; ++i) {
+                const int16_t *srow = tab[g_class[rd[i]]];
+                int32_t hdiag = H[0], hleft = 0, e = ninf;
+                for (int j = 0; j < F; ++j) {
+                    const int32_t hup = H[j + 1];
+                    e = (e + eR > hleft + oR) ? e + eR : hleft + oR;
+                    const int32_t f = (Fv[j + 1] + eF > hup + oF) ? Fv[j + 1] + eF : hup + oF;
+                    int32_t h = hdiag + srow[g_class[rf[j]]];
+                    if (e > h) h = e;
+                    if (f > h) h = f;
+                    if (alg == 0) { if (h < 0) h = 0; if (h > best) best = h; }
+                    Fv[j + 1] = f;
+                    hdiag = hup;
+                    H[j + 1] = h;
+                    hleft = h;
+                }
+                H[0] = 0;
+                if (alg == 1 && H[F] > best) best = H[F];
+            }
+            if (alg == 1) for (int j = 0; j <= F; ++j) if (H[j] > best) best = H[j];
+            scores[p] = (int16_t)(best > 32767 ? 32767 : best);
+        }
+        free(Fv);
+        free(H);
+    }
+    return n;
+}
+
+
 /* ---- affine-gap alignments (extension, no reference counterpart) ----
  * Three-state Gotoh traceback whose tie-breaks are chosen so that open == extend == g walks
  * exactly the path of the linear model above (the only reference-pinned case):

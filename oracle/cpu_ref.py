@@ -54,7 +54,7 @@ def lib():
         u8p = ctypes.POINTER(ctypes.c_uint8)
         i16p = ctypes.POINTER(ctypes.c_int16)
         sp = ctypes.POINTER(Scoring)
-        for name in ("vref_score", "vref_score_affine", "vref_score_wide"):
+        for name in ("vref_score", "vref_score_affine", "vref_score_wide", "vref_score_affine_wide"):
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, i16p, ctypes.c_int]
@@ -87,7 +87,10 @@ def score(opt, reads, refs, scoring=None, threads=1, affine=False, wide=False):
     n, R = reads.shape
     F = refs.shape[1]
     out = np.zeros(n, dtype=np.int16)
-    fn = lib().vref_score_affine if affine else (lib().vref_score_wide if wide else lib().vref_score)
+    if affine:
+        fn = lib().vref_score_affine_wide if wide else lib().vref_score_affine
+    else:
+        fn = lib().vref_score_wide if wide else lib().vref_score
     fn(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc),
        out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
     return out

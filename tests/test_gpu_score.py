@@ -267,3 +267,27 @@ def test_half_float_and_int16_forms_agree(monkeypatch, aff):
         assert np.array_equal(a, exp) and np.array_equal(b, exp), opt
     fast.close()
     plain.close()
+
+
+def test_small_calls_run_on_the_pinned_staging_directly(monkeypatch):
+    """Calls of a few hundred KB skip the chunk pipeline: the kernels read the gathered sequences out of pinned host
+    memory and (scores) write their results there.  Same results as the pipeline, which VALIGN_HIP_DIRECT_BYTES=0 forces."""
+    R, F, n = 64, 128, 1000                                       # BASELINE configs[0]
+    reads, refs = synth.make_pairs(n, R, F, seed=5, indel_rate=0.03, n_run_frac=0.05, short_frac=0.1)
+    exp = [cpu_ref.score(opt, reads, refs, threads=8) for opt in (0, 1)]
+    exp_rows = [cpu_ref.align(opt, reads, refs, threads=8) for opt in (0, 1)]
+    for direct in (True, False):
+        if not direct:
+            monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")
+        eng = hipkernel.Engine(R, F)
+        for opt in (0, 1):
+            assert np.array_equal(eng.score_host(opt, reads, refs, threads=2), exp[opt])
+            assert eng.describe(opt, n)["direct_call"] == (1 if direct else 0)
+            rows, idx = eng.align_host(opt, reads, refs, threads=2)
+            assert np.array_equal(idx, exp_rows[opt][1]) and np.array_equal(rows, exp_rows[opt][0])
+            assert eng.describe(opt, n)["direct_call"] == (1 if direct else 0)
+        # a large call on the same engine goes through the pipeline again
+        big_r, big_f = np.tile(reads, (40, 1)), np.tile(refs, (40, 1))
+        assert np.array_equal(eng.score_host(0, big_r, big_f, threads=4), np.tile(exp[0], 40))
+        assert eng.describe(0, n)["direct_call"] == 0
+        eng.close()

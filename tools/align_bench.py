@@ -17,18 +17,22 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--geoms", default="0x0")
     ap.add_argument("--policy", type=int, default=0, help="1: SSE/AVX tie-breaks")
+    ap.add_argument("--models", default="linear,affine", help="gap models to time (affine: open -5, extend -1; BASELINE config 3)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     reads, refs = bench.synth_on_device(a.pairs, dev, seed=2000)
     AL = bench.R + bench.F
     rows = torch.empty((a.pairs, 2, AL), dtype=torch.uint8, device=dev)
     idx = torch.empty((a.pairs, 4), dtype=torch.int16, device=dev)
-    for geom in a.geoms.split(","):
+    for geom, model in ((g, m) for g in a.geoms.split(",") for m in a.models.split(",")):
         G, K = (int(x) for x in geom.split("x"))
-        eng = hipkernel.Engine(bench.R, bench.F, group_lanes=G, rows_per_lane=K)
+        if model == "affine" and a.policy:
+            continue
+        sc = hipkernel.Scoring.make(2, -1, -3, -3, **(bench.AFFINE if model == "affine" else {}))
+        eng = hipkernel.Engine(bench.R, bench.F, sc, group_lanes=G, rows_per_lane=K)
         if a.policy:
             eng.set_traceback_policy(a.policy)
-        for opt, name in ((0, "sw"), (1, "nw")):
+        for opt, name in ((0, "sw_" + model), (1, "nw_" + model)):
             eng.align_device(opt, reads, refs, rows, idx)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -221,6 +221,7 @@ public:
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
         double classify_ms = 0;                              // part of gather_ms: trimmed lengths + binning
+        int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly
     };
 
     Engine(int device, int R, int F, const Scoring &sc, int force_g, int force_k)
@@ -243,6 +244,7 @@ public:
         force_g_ = force_g;
         force_k_ = force_k;
         plan_ = choose_plan(R_, F_, force_g, force_k);
+        latency_plan_ = (force_g || force_k || plan_.long_mode) ? plan_ : choose_plan(R_, F_, 0, 0, true);
         build_length_classes();
         for (int s = 0; s < kSlots; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
         for (int s = 0; s < kSlots; ++s) {
@@ -311,7 +313,9 @@ public:
             score_long_device(alg, n, d_reads, d_refs, d_scores, stream, wide);
             return;
         }
-        launch_score(plan_, alg, R_, F_, n, d_reads, d_refs, d_scores, stream);
+        // a batch that leaves most SIMDs with at most one wave is over when its slowest wave is: shortest sweep
+        const bool few = n <= (long long)latency_plan_.pairs_per_wave * 1024 && band_width_ == 0;
+        launch_score(few ? latency_plan_ : plan_, alg, R_, F_, n, d_reads, d_refs, d_scores, stream);
     }
 
     // One launch of the register-sweep score kernel over n pairs of shape R x F (sequences laid
@@ -528,6 +532,25 @@ public:
         ensure_staging(chunk);
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
+        if (direct_call(n, per_pair) && !ragged_applies(alg)) {      // (length-sorted batching is a property of the pipeline)
+            // Small call (the reference's timing loop is 100 of them back to back, src/impl/main.cpp:278-287): what
+            // it costs is API calls, not bytes.  The kernel reads the gathered sequences straight out of the pinned
+            // staging over PCIe and writes its scores into pinned host memory: one launch and one wait instead of
+            // three copies, a launch, an event and four event waits.
+            host_stats_ = HostStats{};
+            auto t0 = std::chrono::steady_clock::now();
+            gather(reads, refs, n, h_reads_[0], h_refs_[0], threads);
+            auto t1 = std::chrono::steady_clock::now();
+            score_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), (int16_t *)dev_view(h_scores_[0]), streams_[0]);
+            hip_check(hipStreamSynchronize(streams_[0]), "hipStreamSynchronize");
+            auto t2 = std::chrono::steady_clock::now();
+            memcpy(scores, h_scores_[0], sizeof(short) * (size_t)n);
+            host_stats_.gather_ms = ms_between(t0, t1);
+            host_stats_.wait_ms = ms_between(t1, t2);
+            host_stats_.drain_ms = ms_between(t2, std::chrono::steady_clock::now());
+            host_stats_.direct = 1;
+            return;
+        }
         const bool ragged = ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
         const bool shared_scratch = plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg);
         host_stats_ = HostStats{};
@@ -621,8 +644,6 @@ public:
         // affine gaps with the traceback information tagged into the cells (4-bit codes, 4-step blocks)
         const bool affine_tagged = sc_.affine && !sse_policy_ && !no_tag_ && affine_tagged_range_ok(alg);
         int blocks8 = affine_tagged ? (F_ + G - 1 + 3) / 4 : (F_ + G - 1 + 7) / 8;            // blocks of steps per lane
-        const int burst = hold_blocks(K);                 // the tagged kernels store this many blocks at a time
-        blocks8 = (blocks8 + burst - 1) / burst * burst;
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
         const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4 * ((sc_.affine && !affine_tagged) ? 2 : 1);
         // Pointer scratch: as much of the batch per launch as memory allows (a 1 M-pair launch keeps
@@ -745,6 +766,34 @@ public:
         threads = std::min(threads, 64);
         hipStream_t kernels = streams_[0], copy_in = streams_[1], copy_out = streams_[2];
         host_stats_ = HostStats{};
+        if (direct_call(n, (size_t)AL)) {
+            // Small call: one stream, no events.  The kernels read the sequences out of the pinned staging; rows
+            // and coordinates land next to each other in one device buffer and come back in ONE copy (scattered
+            // 4-byte stores over PCIe would cost a bus transaction each).
+            auto t0 = std::chrono::steady_clock::now();
+            gather(reads, refs, n, h_reads_[0], h_refs_[0], threads);
+            auto t1 = std::chrono::steady_clock::now();
+            const size_t rows_bytes = ((size_t)n * 2 * AL + 15) / 16 * 16, all_bytes = rows_bytes + sizeof(short) * 4 * (size_t)n;
+            // (the slot's row buffer is sized for `chunk` >= 1024 pairs: rows + coordinates of n <= chunk pairs fit
+            // whenever 8 n <= 2 AL (chunk - n); else the coordinates use their own buffer and a second copy)
+            const bool one_copy = all_bytes <= (size_t)align_staged_pairs_ * 2 * AL;
+            short *d_idx = one_copy ? (short *)(d_rows_[0] + rows_bytes) : d_idx_[0];
+            align_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), d_rows_[0], d_idx, kernels);
+            if (one_copy) {
+                hip_check(hipMemcpyAsync(h_rows_[0], d_rows_[0], all_bytes, hipMemcpyDeviceToHost, kernels), "D2H rows + idx");
+            } else {
+                hip_check(hipMemcpyAsync(h_rows_[0], d_rows_[0], (size_t)n * 2 * AL, hipMemcpyDeviceToHost, kernels), "D2H rows");
+                hip_check(hipMemcpyAsync(h_idx_[0], d_idx_[0], sizeof(short) * 4 * (size_t)n, hipMemcpyDeviceToHost, kernels), "D2H idx");
+            }
+            hip_check(hipStreamSynchronize(kernels), "hipStreamSynchronize");
+            auto t2 = std::chrono::steady_clock::now();
+            scatter(alignments, n, h_rows_[0], one_copy ? (const short *)(h_rows_[0] + rows_bytes) : h_idx_[0], threads);
+            host_stats_.gather_ms = ms_between(t0, t1);
+            host_stats_.wait_ms = ms_between(t1, t2);
+            host_stats_.drain_ms = ms_between(t2, std::chrono::steady_clock::now());
+            host_stats_.direct = 1;
+            return;
+        }
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
             const auto t0 = std::chrono::steady_clock::now();
@@ -800,13 +849,13 @@ public:
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
                  "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-                 "\"score_cells\": \"%s\", \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
                  plan_.long_mode ? 1 : 0, band_width_, ragged_, host_stats_.launches,
                  host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
-                 score_cell_format(opt & 0xF), host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+                 score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
                  host_stats_.drain_ms);
         return buf;
     }
@@ -830,7 +879,9 @@ private:
                                      "than the opening is not an affine model)");
     }
 
-    LaunchPlan choose_plan(int R, int F, int force_g, int force_k) const {
+    // latency: pick for the shortest single sweep (few pairs: every wave has a SIMD to itself and the call takes
+    // as long as one wave does) instead of for the most cell updates per second
+    LaunchPlan choose_plan(int R, int F, int force_g, int force_k, bool latency = false) const {
         LaunchPlan best;
         double best_cost = 0;
         for (int i = 0; i < kNumGeometries; ++i) {
@@ -874,6 +925,7 @@ private:
             if (g.K > 10) per_step *= 1.0 + 0.06 * (g.K - 10);
             double cost = (double)(F + g.G - 1) * per_step * g.G / 2.0;
             if (best_waves < 8) cost *= 1.0 + 0.08 * (8 - best_waves);         // fewer than two waves per SIMD
+            if (latency) cost = (double)(F + g.G - 1) * (g.K * (sc_.affine ? 9.3 : 5.6) + 7.0);
             if (!best.geo || cost < best_cost) {
                 best = p;
                 best_cost = cost;
@@ -899,6 +951,18 @@ private:
         return p;
     }
 
+
+    // Small calls skip the chunk pipeline (VALIGN_HIP_DIRECT_BYTES: sequence bytes up to which they do; 0 = never)
+    bool direct_call(long long n, size_t per_pair) const {
+        return direct_bytes_ > 0 && (size_t)n * per_pair <= direct_bytes_ && n <= staged_pairs_;
+    }
+
+    // device-side address of pinned host memory of this engine (hipHostMalloc: mapped, same address on ROCm)
+    static uint8_t *dev_view(void *pinned) {
+        void *d = nullptr;
+        hip_check(hipHostGetDevicePointer(&d, pinned, 0), "hipHostGetDevicePointer");
+        return (uint8_t *)d;
+    }
 
     // A call that threw in the middle of the pipeline (a HIP error, `too many length groups`) leaves chunks
     // pending in the slots; draining them into the NEXT caller's arrays would write at the old offsets.  Every
@@ -1087,6 +1151,7 @@ private:
         if (const char *m = getenv("VALIGN_HIP_RAGGED_MIN")) ragged_min_ = std::max(1, atoi(m));   // tuning switch
         if (const char *m = getenv("VALIGN_HIP_CHUNK_BYTES")) score_chunk_bytes_ = (size_t)std::max(4096ll, atoll(m));
         if (const char *m = getenv("VALIGN_HIP_ALIGN_CHUNK_BYTES")) align_chunk_bytes_ = (size_t)std::max(4096ll, atoll(m));
+        if (const char *m = getenv("VALIGN_HIP_DIRECT_BYTES")) direct_bytes_ = (size_t)std::max(0ll, atoll(m));
     }
 
     const LaunchPlan &class_plan(int R, int F) {
@@ -1258,6 +1323,7 @@ private:
     int ragged_ = 0, force_g_ = 0, force_k_ = 0;
     size_t score_chunk_bytes_ = 48u << 20;                   // staging chunk of score_host (VALIGN_HIP_CHUNK_BYTES)
     size_t align_chunk_bytes_ = 128u << 20;                  // staging chunk of align_host, inputs + results (VALIGN_HIP_ALIGN_CHUNK_BYTES)
+    size_t direct_bytes_ = 768u << 10;                       // calls with at most this many sequence bytes run on the pinned staging directly
     long long ragged_min_ = 2048;                             // pairs a length bin needs for its own launch
     std::vector<int> read_caps_, ref_caps_;
     std::vector<unsigned char> read_class_;
@@ -1272,7 +1338,7 @@ private:
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     std::string arch_;
-    LaunchPlan plan_;
+    LaunchPlan plan_, latency_plan_;
     hipStream_t streams_[kSlots] = {};
     hipEvent_t slot_done_[kSlots] = {};
     long long slot_begin_[kSlots] = {}, slot_pending_[kSlots] = {};

@@ -36,7 +36,7 @@ struct EndCell {          // per pair, 8 bytes
 struct FillArgs {
     const uint8_t *reads;
     const uint8_t *refs;
-    unsigned *ptr;            // pointer scratch: [pair-of-pairs][lane][block of 8 steps][K] dwords
+    unsigned *ptr;            // pointer scratch: [wave][block of steps][lane of the wave][words per block] dwords
     EndCell *ends;            // n
     long long n;
     int R, F;
@@ -52,6 +52,38 @@ __device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
 }
 __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
     return (s16x2)((u16x2)a * (u16x2)b + (u16x2)c);
+}
+
+// POINTER STREAM LAYOUT: [wave][block of steps][lane of the wave][W words], W = K (2K for the two-stream affine
+// kernel).  What a wave stores for one block of steps -- 64 lanes x W dwords -- is ONE contiguous run (2.5 KB at
+// K = 10): neighbouring lanes fill each other's 32-byte sectors and DRAM sees whole pages, where the lane-major
+// layout of round 1 ([pair-of-pairs][lane][block][W]) scattered a wave's store over 64 places 5 KB apart (its
+// HBM write traffic came out 1.2-1.7x the useful bytes even with four blocks parked in registers per burst).
+template <int G, int K, int W>
+__device__ __forceinline__ unsigned *pointer_stream_lane(unsigned *base, long long pair0, int blocks, int lane) {
+    const long long wave = pair0 / Geo<G, K>::kPairs;
+    return base + (wave * blocks * kWave + lane) * (long long)W;
+}
+// block b of the lane's stream (the stride between a lane's blocks is one wave-wide run)
+template <int W>
+__device__ __forceinline__ unsigned *pointer_stream_block(unsigned *lane_base, long long block) {
+    return lane_base + block * (long long)(kWave * W);
+}
+// W dwords at an 8-byte aligned address (W is even: K is): 8-byte stores
+template <int W>
+__device__ __forceinline__ void store_block_words(unsigned *dst, const unsigned (&w)[W]) {
+    static_assert(W % 2 == 0, "rows per lane are even");
+#pragma unroll
+    for (int i = 0; i < W / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+}
+
+// One block of steps of a lane is complete: store its K words (wave-contiguous layout above).
+template <int K>
+__device__ __forceinline__ void finish_block(unsigned *lane_base, long long block, const s16x2 (&acc)[K]) {
+    unsigned w[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) w[q] = as_u32(acc[q]);
+    store_block_words<K>(pointer_stream_block<K>(lane_base, block), w);
 }
 
 // End cell of each of the two pairs of a lane group, from the per-row first arg-max registers
@@ -195,8 +227,7 @@ align_fill_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    const long long pp = w.pair0 / 2 + grp;       // pair-of-pairs index of this lane group
-    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
 
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -276,9 +307,10 @@ align_fill_kernel(const FillArgs args) {
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
         if ((t & 7) == 7) {
-            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
+            unsigned w8[K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+            for (int q = 0; q < K; ++q) w8[q] = as_u32(acc[q]);
+            store_block_words<K>(pointer_stream_block<K>(ptr_lane, t >> 3), w8);
         }
         ++j;
         code_addr += 2;
@@ -297,53 +329,6 @@ align_fill_kernel(const FillArgs args) {
     for (; t < steps; ++t) step(std::true_type{}, t);
 
     write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
-}
-
-// Pointer words leave the lane in bursts of whole 32-byte sectors: a lane's K dwords per block (40 bytes at
-// K = 10) dirty partial sectors, L2 evicts them half written and the HBM write traffic comes out 1.7x the
-// useful bytes (PMC WRITE_SIZE / TCC_EA0_WRREQ) -- and these kernels run against the write path.  kHoldBlocks
-// consecutive blocks (contiguous in the lane's region) are therefore kept in registers and stored together
-// as 16-byte words: 160 bytes = five full sectors at K = 10.
-constexpr int hold_blocks(int K) {
-    int g = 8, k = K;
-    while (k) { const int r = g % k; g = k; k = r; }      // gcd(K, 8)
-    return 8 / g;
-}
-
-template <int K, int NB>
-__device__ __forceinline__ void store_held_blocks(unsigned *dst, const s16x2 (&hold)[(NB > 1 ? NB - 1 : 1) * K], const s16x2 (&acc)[K]) {
-    unsigned w[NB * K];
-#pragma unroll
-    for (int i = 0; i < (NB - 1) * K; ++i) w[i] = as_u32(hold[i]);
-#pragma unroll
-    for (int q = 0; q < K; ++q) w[(NB - 1) * K + q] = as_u32(acc[q]);
-    static_assert(NB == 1 || (NB * K) % 4 == 0, "a burst is a whole number of 16-byte words");
-#pragma unroll
-    for (int i = 0; i < NB * K / 4; ++i)
-        reinterpret_cast<uint4 *>(dst)[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-
-// block `b` (wave-uniform) of a burst is complete: park it, or store the whole burst with it
-template <int K, int NB>
-__device__ __forceinline__ void finish_block(unsigned *lane_base, long long block, s16x2 (&hold)[(NB > 1 ? NB - 1 : 1) * K],
-                                             const s16x2 (&acc)[K]) {
-    if constexpr (NB == 1) {
-        unsigned *dst = lane_base + block * K;
-#pragma unroll
-        for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
-        return;
-    }
-    const int b = (int)(block % NB);
-    if (b == NB - 1) {
-        store_held_blocks<K, NB>(lane_base + (block - (NB - 1)) * K, hold, acc);
-    } else {
-#pragma unroll
-        for (int x = 0; x < NB - 1; ++x)
-            if (b == x) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) hold[x * K + q] = acc[q];
-            }
-    }
 }
 
 // Linear gaps, Default tie-breaks, with the back pointer carried INSIDE the cell value: every value
@@ -407,10 +392,7 @@ align_fill_tag_kernel(const FillArgs args) {
         jr[half] = w.first_bad[2 * p_local + 1];
     }
 
-    // (one block per store here: this kernel is bound by VALU issue, and parking blocks costs more moves than
-    // the fuller sectors save -- measured 18.1 vs 18.6 ms; the 4-step blocks of the affine kernel do gain)
-    constexpr int kHold = 1;
-    s16x2 Hl[K], tag[K], acc[K], hold[K];
+    s16x2 Hl[K], tag[K], acc[K];
     constexpr int kTracked = (ALG == kAlgSW && !LANEKEY) ? K : 1;
     s16x2 rb[kTracked], fc[kTracked], sel[ALG == kAlgNW ? K : 1];
     s16x2 row_key[LANEKEY ? K : 1];              // 2^b - 1 - q: the earlier row wins among equal values
@@ -450,8 +432,7 @@ align_fill_tag_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    const long long pp = w.pair0 / 2 + grp;
-    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
 
     // LDS fetches run one step ahead of the arithmetic, as in score_kernel: raw profile dwords of this
     // step in registers, rows of step t+1 and slab numbers of step t+2 requested now (every lane, every
@@ -549,13 +530,12 @@ align_fill_tag_kernel(const FillArgs args) {
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, tag[q]);
-        if ((t & 7) == 7) finish_block<K, kHold>(ptr_lane, t >> 3, hold, acc);
+        if ((t & 7) == 7) finish_block<K>(ptr_lane, t >> 3, acc);
         ++j;
         code_addr += 2;
     };
 
-    // whole bursts: args.blocks8 is a multiple of kHold (hip_engine.hip.h)
-    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 8 * kHold - 1) / (8 * kHold)) * (8 * kHold) : args.blocks8 * 8;
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;      // whole blocks
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
     auto sweep = [&](auto last_only_tag) __attribute__((always_inline)) {
@@ -662,8 +642,7 @@ align_fill_affine_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    const long long pp = w.pair0 / 2 + grp;
-    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * (2 * K);
+    unsigned *ptr_lane = pointer_stream_lane<G, K, 2 * K>(args.ptr, w.pair0, args.blocks8, lane);
 
     // LDS fetches run one step ahead of the arithmetic, as in score_kernel: raw profile dwords of this
     // step in registers, rows of step t+1 and slab numbers of step t+2 requested now (every lane, every
@@ -746,11 +725,12 @@ align_fill_affine_kernel(const FillArgs args) {
             acc_g[q] = pk_mad_u(acc_g[q], four, code_g[q]);
         }
         if ((t & 7) == 7) {
-            unsigned *dst = ptr_lane + (long long)(t >> 3) * (2 * K);
+            unsigned w8[2 * K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc_h[q]);
+            for (int q = 0; q < K; ++q) w8[q] = as_u32(acc_h[q]);
 #pragma unroll
-            for (int q = 0; q < K; ++q) dst[K + q] = as_u32(acc_g[q]);
+            for (int q = 0; q < K; ++q) w8[K + q] = as_u32(acc_g[q]);
+            store_block_words<2 * K>(pointer_stream_block<2 * K>(ptr_lane, t >> 3), w8);
         }
         ++j;
         code_addr += 2;
@@ -834,8 +814,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         jr[half] = w.first_bad[2 * p_local + 1];
     }
 
-    constexpr int kHold = hold_blocks(K);
-    s16x2 Hl[K], El[K], HOl[SYM ? K : 1], code[K], acc[K], hold[(kHold > 1 ? kHold - 1 : 1) * K];
+    s16x2 Hl[K], El[K], HOl[SYM ? K : 1], code[K], acc[K];
     s16x2 rb[1], fc[1], sel[ALG == kAlgNW ? K : 1], row_key[LANEKEY ? K : 1];
     short nw_seed[2] = {0, 0};
 #pragma unroll
@@ -869,8 +848,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    const long long pp = w.pair0 / 2 + grp;
-    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;     // blocks8: 4-step blocks here
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);     // blocks8: 4-step blocks here
 
     unsigned pa[K / 2], pb[K / 2];
     unsigned ca_next, cb_next;
@@ -956,12 +934,12 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], sixteen, code[q]);
-        if ((t & 3) == 3) finish_block<K, kHold>(ptr_lane, t >> 2, hold, acc);
+        if ((t & 3) == 3) finish_block<K>(ptr_lane, t >> 2, acc);
         ++j;
         code_addr += 2;
     };
 
-    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 4 * kHold - 1) / (4 * kHold)) * (4 * kHold) : args.blocks8 * 4;
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 3) / 4) * 4 : args.blocks8 * 4;      // whole blocks
     const int fill_end = G - 1 < steps ? G - 1 : steps;
     const int steady_end = F > fill_end ? F : fill_end;
     auto sweep = [&](auto last_only_tag) __attribute__((always_inline)) {
@@ -1063,8 +1041,7 @@ align_fill_sse_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    const long long pp = w.pair0 / 2 + grp;
-    unsigned *ptr_lane = args.ptr + ((pp * G + l) * (long long)args.blocks8) * K;
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
 
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -1114,9 +1091,10 @@ align_fill_sse_kernel(const FillArgs args) {
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
         if ((t & 7) == 7) {
-            unsigned *dst = ptr_lane + (long long)(t >> 3) * K;
+            unsigned w8[K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) dst[q] = as_u32(acc[q]);
+            for (int q = 0; q < K; ++q) w8[q] = as_u32(acc[q]);
+            store_block_words<K>(pointer_stream_block<K>(ptr_lane, t >> 3), w8);
         }
         ++j;
         code_addr += 2;
@@ -1173,8 +1151,10 @@ traceback_kernel(const TraceArgs a) {
     uint8_t *row_read = a.rows + pair * 2 * AL;
     uint8_t *row_ref = row_read + AL;
     const EndCell e = a.ends[pair];
-    const unsigned *ptr_pair = a.ptr + ((pair >> 1) * G) * (long long)a.blocks8 * wpb;
-    const long long ptr_words = (long long)G * a.blocks8 * wpb;   // words of this pair-of-pairs
+    // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
+    const int ppw = 2 * (kWave / G);
+    const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
+    const long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
     const int half_shift = (int)(pair & 1) * 16;
 
     int i = e.read_pos, j = e.ref_pos, h = e.score;
@@ -1239,7 +1219,7 @@ traceback_kernel(const TraceArgs a) {
             const int p = i + a.pad_rows;
             const int l = p / K, q = p - l * K;
             const int t = j + l;
-            const long long wi = ((long long)l * a.blocks8 + (a.tagged == 2 ? (t >> 2) : (t >> 3))) * wpb + q;
+            const long long wi = ((long long)(a.tagged == 2 ? (t >> 2) : (t >> 3)) * kWave + l) * wpb + q;
             if (a.tagged == 2) {
                 const int f4 = code_at(wi, t);          // [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
                 if (state == 0) {
