@@ -654,6 +654,61 @@ int vref_score_banded_sw(int n, int R, int F, const uint8_t *reads, const uint8_
     return n;
 }
 
+/* The same band with affine gaps (Gotoh recurrence as vref_score_affine_wide; cells outside the band count as
+ * H = 0, E = F = 0 -- Smith-Waterman's own floor -- and cannot hold the maximum).                              */
+int vref_score_banded_sw_affine(int n, int R, int F, const uint8_t *reads, const uint8_t *refs, const vref_scoring *sc,
+                                int block_rows, int col_align, int band_half, int16_t *scores, int threads) {
+    class_init();
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int oR = sc->open_read, eR = sc->ext_read, oF = sc->open_ref, eF = sc->ext_ref;
+    if (block_rows < 1) block_rows = 1;
+    if (col_align < 1) col_align = 1;
+    const int blocks = R > 0 ? (R + block_rows - 1) / block_rows : 1;
+    const int pad = blocks * block_rows - R;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *fprev = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+        int32_t *fcur = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(prev, 0, sizeof(int32_t) * (size_t)(F + 1));
+            memset(fprev, 0, sizeof(int32_t) * (size_t)(F + 1));
+            int32_t best = 0;
+            for (int i = 0; i < R; ++i) {
+                int lo, hi;
+                band_columns((i + pad) / block_rows, R, F, block_rows, col_align, pad, band_half, &lo, &hi);
+                memset(cur, 0, sizeof(int32_t) * (size_t)(F + 1));
+                memset(fcur, 0, sizeof(int32_t) * (size_t)(F + 1));
+                const int16_t *srow = tab[g_class[rd[i]]];
+                int32_t e = 0;
+                for (int j = lo; j <= hi; ++j) {
+                    e = (e + eR > cur[j] + oR) ? e + eR : cur[j] + oR;
+                    if (e < 0) e = 0;
+                    int32_t f = (fprev[j + 1] + eF > prev[j + 1] + oF) ? fprev[j + 1] + eF : prev[j + 1] + oF;
+                    if (f < 0) f = 0;
+                    int32_t h = prev[j] + srow[g_class[rf[j]]];
+                    if (e > h) h = e;
+                    if (f > h) h = f;
+                    if (h < 0) h = 0;
+                    cur[j + 1] = h;
+                    fcur[j + 1] = f;
+                    if (h > best) best = h;
+                }
+                int32_t *t = prev; prev = cur; cur = t;
+                t = fprev; fprev = fcur; fcur = t;
+            }
+            scores[p] = (int16_t)(best > 32767 ? 32767 : best);
+        }
+        free(fcur); free(fprev); free(cur); free(prev);
+    }
+    return n;
+}
+
 /* ---- int32 cells (extension): the same two score recurrences without the reference's int16
  * wrap-around, for (shape, scoring) whose cells leave int16; results saturate at 32767, the
  * largest score the ABI's short can carry.                                                   */

@@ -62,8 +62,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, u8p, i16p, ctypes.c_int]
-        L.vref_score_banded_sw.restype = ctypes.c_int
-        L.vref_score_banded_sw.argtypes = [ctypes.c_int] * 3 + [u8p, u8p, sp, ctypes.c_int, ctypes.c_int, ctypes.c_int, i16p, ctypes.c_int]
+        for name in ("vref_score_banded_sw", "vref_score_banded_sw_affine"):
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_int] * 3 + [u8p, u8p, sp, ctypes.c_int, ctypes.c_int, ctypes.c_int, i16p, ctypes.c_int]
         L.vref_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -96,7 +98,7 @@ def score(opt, reads, refs, scoring=None, threads=1, affine=False, wide=False):
     return out
 
 
-def score_banded_sw(reads, refs, band_width, scoring=None, threads=1, block_rows=1, col_align=1):
+def score_banded_sw(reads, refs, band_width, scoring=None, threads=1, block_rows=1, col_align=1, affine=False):
     """Banded Smith-Waterman scores (extension), band_width diagonals, 0 = every cell.  The default
     (block_rows = 1, col_align = 1) is the per-cell band |j - floor(i * F / R)| <= band_width / 2;
     libHIPKernel.so's documented band is block_rows = VALIGN_HIP_BAND_BLOCK_ROWS, col_align =
@@ -106,7 +108,8 @@ def score_banded_sw(reads, refs, band_width, scoring=None, threads=1, block_rows
     n, R = reads.shape
     F = refs.shape[1]
     out = np.zeros(n, dtype=np.int16)
-    lib().vref_score_banded_sw(n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), block_rows, col_align,
+    fn = lib().vref_score_banded_sw_affine if affine else lib().vref_score_banded_sw
+    fn(n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), block_rows, col_align,
                                band_width // 2 if band_width > 0 else -1,
                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
     return out

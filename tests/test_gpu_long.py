@@ -214,3 +214,76 @@ def test_long_path_over_many_staging_chunks(forced_long, monkeypatch):
             exp = cpu_ref.score(opt, r0, f0, threads=8)
             got = hip.score_alignments(opt, reads, refs)
             assert np.array_equal(got, np.tile(exp, 4)), opt
+
+
+AFFINE_SETS = [(-5, -1, -5, -1), (-6, -2, -4, -1), (-3, -3, -3, -3)]
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 11), (161, 700, 33, 13), (400, 333, 40, 14), (1000, 1300, 17, 16)])
+@pytest.mark.parametrize("aff", AFFINE_SETS)
+def test_forced_long_path_affine_matches_oracle(forced_long, R, F, n, seed, aff):
+    """Affine gaps on the strip kernel (E in registers along the row, F handed from strip to strip next to H):
+    shapes that also fit the resident kernel, forced onto the long path, against the Gotoh oracle (which the
+    enumeration fixtures pin) -- and open == extend against the linear oracle."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.05, short_frac=0.08,
+                                   lowercase_frac=0.05, junk_frac=0.05)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        for opt in (0, 1):
+            got = hip.score_alignments(opt, reads, refs)
+            exp = cpu_ref.score(opt, reads, refs, sc, threads=8, affine=True)
+            assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8], got[:8], exp[:8])
+            if aff[0] == aff[1] and aff[2] == aff[3]:
+                assert np.array_equal(got, cpu_ref.score(opt, reads, refs, cpu_ref.Scoring.make(2, -1, aff[0], aff[2]), threads=8))
+        assert '"long_mode": 1' in hip.drain_log()
+
+
+@pytest.mark.parametrize("R,F,n", [(3000, 3500, 10), (2500, 700, 9)])
+def test_long_shapes_affine(R, F, n):
+    """Shapes that need row strips, affine gaps, both cell widths (int16 where the range allows, int32 forced)."""
+    reads, refs = synth.make_pairs(n, R, F, seed=R + 1, indel_rate=0.02, n_run_frac=0.1, short_frac=0.1)
+    aff = (-5, -1, -5, -1)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    for width in (0, 32):
+        with host.Plugin(build.HIP_PLUGIN, R, F, score_width=width, **keys) as hip:
+            for opt in (0, 1):
+                got = hip.score_alignments(opt, reads, refs)
+                assert np.array_equal(got, cpu_ref.score(opt, reads, refs, sc, threads=8, affine=True, wide=True)), (width, opt)
+
+
+def test_config5_shape_affine_and_banded_affine():
+    """10 kbp x 10 kbp with the affine scoring of BASELINE configs 2-4: unbanded SW (int16 cells suffice), the NW
+    variant (cells dip below int16: the engine must pick int32 by itself), and the 512-diagonal band."""
+    R = F = 10000
+    n = 5
+    reads, refs = synth.make_pairs(n, R, F, seed=59, sub_rate=0.1, indel_rate=0.01, n_run_frac=0.2, short_frac=0.2)
+    aff = (-5, -1, -5, -1)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    block_rows, col_align = band_constants()
+    with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+        assert np.array_equal(hip.score_alignments(0, reads, refs), cpu_ref.score(0, reads, refs, sc, threads=8, affine=True, wide=True))
+        assert '"score_cells": "int16"' in hip.drain_log()
+        assert np.array_equal(hip.score_alignments(1, reads, refs), cpu_ref.score(1, reads, refs, sc, threads=8, affine=True, wide=True))
+        assert '"score_cells": "int32"' in hip.drain_log()
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512, **keys) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    exp = cpu_ref.score_banded_sw(reads, refs, 512, sc, threads=8, block_rows=block_rows, col_align=col_align, affine=True)
+    assert np.array_equal(got, exp)
+    assert (cpu_ref.score_banded_sw(reads, refs, 512, sc, threads=8, affine=True) <= got).all()
+    assert (got <= cpu_ref.score(0, reads, refs, sc, threads=8, affine=True, wide=True)).all()
+
+
+@pytest.mark.parametrize("band", [16, 64, 512])
+def test_banded_affine(band):
+    R, F, n = 1000, 1300, 33
+    reads, refs = synth.make_pairs(n, R, F, seed=21, indel_rate=0.03, n_run_frac=0.05, short_frac=0.08)
+    aff = (-6, -2, -4, -1)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    block_rows, col_align = band_constants()
+    with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band, **keys) as hip:
+        got = hip.score_alignments(0, reads, refs)
+    assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, band, sc, threads=8, block_rows=block_rows, col_align=col_align, affine=True))

@@ -111,8 +111,11 @@ constexpr int kMaxBlockLds = 160 * 1024;       // gfx950: 160 KiB per CU, one bl
 constexpr int kSlots = 4;                      // staging slots of the host-pointer pipeline
 constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribute must be raised
 
-// Long-read path (row strips + column phases, long_kernels.hip.h): one geometry, linear gaps.
+// Long-read path (row strips + column phases, long_kernels.hip.h): one geometry.
 constexpr int kLongG = 16, kLongK = 10;
+static const void *const kLongAffineKernels[2][2] = {       // [alg][int32 cells]
+    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true, true>},
+    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true, true>}};
 static const void *const kLongKernels[2][2][2] = {     // [alg][gap_read == gap_ref][int32 cells]
     {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true>},
      {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true>}},
@@ -388,9 +391,6 @@ public:
                            hipStream_t stream, bool wide) {
         if (band_width_ > 0 && alg != kAlgSW)
             throw std::runtime_error("band_width applies to Smith-Waterman scores only");
-        if (sc_.affine)
-            throw std::runtime_error("the long-read path implements the linear gap model only (read_length " +
-                                     std::to_string(R_) + " needs row strips)");
         const int rows = kLongG * kLongK;
         const int ppw = 2 * (kWave / kLongG);
         LongArgs a;
@@ -403,7 +403,12 @@ public:
         a.mismatch = (short)sc_.mismatch;
         a.gap_read = (short)sc_.gap_read;
         a.gap_ref = (short)sc_.gap_ref;
-        const size_t bytes_per_wave = (size_t)2 * (ppw / 2) * a.row_dwords * 4 * (wide ? 2 : 1);
+        a.open_read = (short)sc_.open_read;
+        a.ext_read = (short)sc_.ext_read;
+        a.open_ref = (short)sc_.open_ref;
+        a.ext_ref = (short)sc_.ext_ref;
+        const int row_sets = (wide ? 2 : 1) * (sc_.affine ? 2 : 1);        // boundary rows per pair-of-pairs: per half (int32), H and F (affine)
+        const size_t bytes_per_wave = (size_t)2 * (ppw / 2) * a.row_dwords * 4 * row_sets;
         long long chunk = (long long)((8ull << 30) / bytes_per_wave) * ppw;
         chunk = std::max<long long>(ppw, std::min(chunk, (n + ppw - 1) / ppw * ppw));
         const long long waves = chunk / ppw;
@@ -414,7 +419,8 @@ public:
             brow_bytes_ = (size_t)waves * bytes_per_wave;
             hip_check(hipMalloc((void **)&d_brow_, brow_bytes_), "hipMalloc(boundary rows)");
         }
-        const void *fn = kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
+        const void *fn = sc_.affine ? kLongAffineKernels[alg][wide ? 1 : 0]
+                                    : kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
         const int long_lds = LongLds<kLongG, kLongK>::kTotal;
         for (long long begin = 0; begin < n; begin += chunk) {
             const long long cnt = std::min(chunk, n - begin);
@@ -423,7 +429,7 @@ public:
             a.scores = d_scores + begin;
             a.brow = d_brow_;
             a.n = cnt;
-            a.pp_total = waves * (ppw / 2) * (wide ? 2 : 1);
+            a.pp_total = waves * (ppw / 2) * row_sets;
             void *kargs[] = {&a};
             hip_check(hipLaunchKernel(fn, dim3((unsigned)((cnt + ppw - 1) / ppw)), dim3(kWave), kargs,
                                       (size_t)long_lds, stream),

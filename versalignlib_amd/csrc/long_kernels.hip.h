@@ -15,6 +15,9 @@
 //     [center(first row) - w, center(last row) + w], center(r) = r * F / R; every cell outside
 //     these per-strip rectangles counts as 0.  w >= max(R, F) is the unbanded computation.
 //
+//   * AFFINE gaps: E lives in registers like H (one value per row, carried along the row); F runs down the
+//     column, so the strip's bottom row hands BOTH H and F to the next strip (two boundary rows, two ring pairs).
+//
 // Traffic per pair: F bytes of reference per strip + 8 bytes per column and strip of boundary
 // rows; at 10k x 10k that is 0.007 B per cell -- this path stays VALU bound as well.
 #pragma once
@@ -42,6 +45,7 @@ struct LongArgs {
                                // the diagonal through its rows (cells outside count as 0; SW only)
     short match, mismatch;
     short gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;     // affine instantiations (Gotoh, as score_kernel's kGapAffine)
 };
 
 // DP cell representation of the long-read kernel.  Packed: two pairs per register, int16 (the
@@ -55,6 +59,8 @@ struct Cell<false> {
     static __device__ __forceinline__ T bc(int v) { return pk((short)v); }
     static __device__ __forceinline__ T mx(T a, T b) { return pk_max(a, b); }
     static __device__ __forceinline__ T sub0(T a, T g) { return pk_sub_floor0(a, g); }
+    static __device__ __forceinline__ T adds(T a, T c) { return pk_add_sat(a, c); }      // "minus infinity" must not wrap
+    static __device__ __forceinline__ T ninf() { return pk(kNegInf); }
     static __device__ __forceinline__ unsigned bits(T v) { return as_u32(v); }
     static __device__ __forceinline__ T from_bits(unsigned v) { return as_pk(v); }
 };
@@ -64,6 +70,8 @@ struct Cell<true> {
     static __device__ __forceinline__ T bc(int v) { return v; }
     static __device__ __forceinline__ T mx(T a, T b) { return a > b ? a : b; }
     static __device__ __forceinline__ T sub0(T a, T g) { const int d = a - g; return d > 0 ? d : 0; }
+    static __device__ __forceinline__ T adds(T a, T c) { return a + c; }
+    static __device__ __forceinline__ T ninf() { return -(1 << 29); }
     static __device__ __forceinline__ unsigned bits(T v) { return (unsigned)v; }
     static __device__ __forceinline__ T from_bits(unsigned v) { return (int)v; }
 };
@@ -74,7 +82,9 @@ struct LongLds {
     static constexpr int kCodes = geo::kProfBytes;                        // [groups][kRing][2] bytes
     static constexpr int kIn = kCodes + geo::kGroups * kRing * 2;         // [groups][kRing] dwords
     static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
-    static constexpr int kTotal = kOut + geo::kGroups * kRing * 4;
+    static constexpr int kInF = kOut + geo::kGroups * kRing * 4;          // affine: the F values of the boundary rows, same rings
+    static constexpr int kOutF = kInF + geo::kGroups * kRing * 4;
+    static constexpr int kTotal = kOutF + geo::kGroups * kRing * 4;
 };
 
 // Columns [c_lo, c_hi] swept by strip s.  c_lo is a multiple of 4 (16-byte ring accesses).
@@ -96,7 +106,9 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
     c_hi = (int)(hi > F - 1 ? F - 1 : hi);
 }
 
-template <int G, int K, int ALG, bool SYM, bool WIDE>
+// AFFINE: Gotoh recurrence (E along the row in registers like H; F down the column -- through the lanes by DPP
+// and from strip to strip through a second boundary row next to H's).  SYM is ignored then.
+template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 score_long_kernel(const LongArgs args) {
     using geo = Geo<G, K>;
@@ -117,20 +129,33 @@ score_long_kernel(const LongArgs args) {
     unsigned char *codes = valign_smem + lay::kCodes;
     unsigned *ring_in = reinterpret_cast<unsigned *>(valign_smem + lay::kIn);
     unsigned *ring_out = reinterpret_cast<unsigned *>(valign_smem + lay::kOut);
+    unsigned *ring_in_f = reinterpret_cast<unsigned *>(valign_smem + lay::kInF);
+    unsigned *ring_out_f = reinterpret_cast<unsigned *>(valign_smem + lay::kOutF);
 
     const unsigned lane_base = lds_offset(prof) + l * geo::kLaneBytes;
     const unsigned codes_base = lds_offset(codes) + grp * (kRing * 2);
     const unsigned in_base = lds_offset(ring_in) + grp * (kRing * 4);
+    const unsigned in_base_f = lds_offset(ring_in_f) + grp * (kRing * 4);
     unsigned *out_grp = ring_out + grp * kRing;
+    unsigned *out_grp_f = ring_out_f + grp * kRing;
     const long long pp0 = pair0 / 2;                                      // first pair-of-pairs of the wave
 
     const cell_t g_read = ops::bc(ALG == kAlgSW ? -args.gap_read : args.gap_read);
     const cell_t g_ref = ops::bc(ALG == kAlgSW ? -args.gap_ref : args.gap_ref);
+    // affine: magnitudes for the SW floor-at-zero subtract, signed addends for the NW variant (as score_kernel)
+    const cell_t o_read = ops::bc(ALG == kAlgSW ? -args.open_read : args.open_read), e_read = ops::bc(ALG == kAlgSW ? -args.ext_read : args.ext_read);
+    const cell_t o_ref = ops::bc(ALG == kAlgSW ? -args.open_ref : args.open_ref), e_ref = ops::bc(ALG == kAlgSW ? -args.ext_ref : args.ext_ref);
+    const cell_t border_f = (AFFINE && ALG == kAlgNW) ? ops::ninf() : ops::bc(0);     // gap matrices start at minus infinity (NW)
+    const unsigned border_f_bits = ops::bits(border_f);
+    // boundary-row slot of lane group g: H, and next to it F (affine); wide cells keep one per half
+    auto brow_slot_of = [&](int g, int half_, int is_f) __attribute__((always_inline)) -> long long {
+        return ((pp0 + g) * (WIDE ? 2 : 1) + (WIDE ? half_ : 0)) * (AFFINE ? 2 : 1) + is_f;
+    };
 
   // wide cells: the group's two pairs take turns (half 0, then half 1); packed cells: one pass
   for (int half = 0; half < (WIDE ? 2 : 1); ++half) {
     cell_t best = ops::bc(0), col_best = ops::bc(0), row_best = ops::bc(0);
-    const long long brow_slot = WIDE ? (pp0 + grp) * 2 + half : (pp0 + grp);   // boundary row of this sweep
+    const long long brow_slot = brow_slot_of(grp, half, 0);                    // boundary row of this sweep
 
     for (int i = lane; i < geo::kPairStride / 4; i += kWave)
         reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
@@ -170,6 +195,10 @@ score_long_kernel(const LongArgs args) {
         for (int q = 0; q < K; ++q) Hl[q] = ops::bc(0);
 #pragma unroll
         for (int q = 0; q < ((SYM && WIDE && ALG == kAlgSW) ? K : 1); ++q) Gl[q] = 0;
+        cell_t El[AFFINE ? K : 1];
+#pragma unroll
+        for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = border_f;
+        cell_t f_last = border_f;
         cell_t up0 = ops::bc(0), h_last = ops::bc(0);
         if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
             up0 = ops::from_bits(__builtin_nontemporal_load(brow_prev + brow_slot * args.row_dwords + (c_lo - 1)));
@@ -188,6 +217,12 @@ score_long_kernel(const LongArgs args) {
             const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
             const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
             up0 = ops::from_bits(l == 0 ? from_ring : from_lane);
+            cell_t fup0 = border_f;
+            if constexpr (AFFINE) {
+                const unsigned f_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(f_last), 0x138, 0xF, 0xF, true);
+                const unsigned f_ring = *(lds_cu32 *)(in_base_f + (((c_lo + t) & (kRing - 1)) << 2));
+                fup0 = ops::from_bits(l == 0 ? f_ring : f_lane);
+            }
             // LDS fetches run ahead of the arithmetic (every lane, every step): the raw profile dwords of
             // this step are in registers, the rows of step t+1 and the slab numbers of step t+2 are
             // requested now.  The ring refill leads the phase by kLead columns for that.
@@ -213,7 +248,31 @@ score_long_kernel(const LongArgs args) {
                 // column-independent work of row q+1 sits between the links of the dependent chain of
                 // row q (see score_kernel)
                 cell_t h = up0;
-                if constexpr (SYM && WIDE && ALG == kAlgSW) {
+                if constexpr (AFFINE) {
+                    // E, diag + S and their maximum of row q + 1 only need the previous column: computed one row
+                    // ahead, between the links of the dependent chain F -> H down the column (see score_kernel)
+                    auto pass1 = [&](int q) __attribute__((always_inline)) -> cell_t {
+                        const cell_t d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                        const cell_t e = (ALG == kAlgSW) ? ops::mx(ops::sub0(El[q], e_read), ops::sub0(Hl[q], o_read))
+                                                         : ops::mx(ops::adds(El[q], e_read), ops::adds(Hl[q], o_read));
+                        El[q] = e;
+                        if (ALG == kAlgSW) best = ops::mx(best, d);
+                        return ops::mx(d, e);
+                    };
+                    cell_t f = fup0;
+                    cell_t m_cur = pass1(0);
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        f = (ALG == kAlgSW) ? ops::mx(ops::sub0(f, e_ref), ops::sub0(h, o_ref))
+                                            : ops::mx(ops::adds(f, e_ref), ops::adds(h, o_ref));
+                        cell_t m_next = ops::bc(0);
+                        if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] is overwritten
+                        h = ops::mx(m_cur, f);
+                        Hl[q] = h;
+                        m_cur = m_next;
+                    }
+                    f_last = f;
+                } else if constexpr (SYM && WIDE && ALG == kAlgSW) {
                     // int32 cells have a three-operand maximum and a saturating subtract: each cell keeps
                     // (h, max(h - g, 0)) and h = max3(diag + S, left', up') on the floored registers is
                     // non-negative by construction -- add, max3, sub-clamp per cell instead of add, max, sub,
@@ -277,6 +336,7 @@ score_long_kernel(const LongArgs args) {
                 h_last = h;
                 if (l == G - 1) {
                     out_grp[j & (kRing - 1)] = ops::bits(h);               // bottom row of the strip
+                    if constexpr (AFFINE) out_grp_f[j & (kRing - 1)] = ops::bits(f_last);
                     if (ALG == kAlgNW) row_best = ops::mx(row_best, h);
                 }
             }
@@ -289,7 +349,7 @@ score_long_kernel(const LongArgs args) {
         // LDS rings when it is done (commit): a wave never waits for its own refill, which cost a
         // third of the cycles when the loads were issued and consumed in one go.
         unsigned char pre_base[8];
-        u32x4 pre_brow = {0u, 0u, 0u, 0u};
+        u32x4 pre_brow = {0u, 0u, 0u, 0u}, pre_frow = {0u, 0u, 0u, 0u};
         bool pre_brow_valid = false;
         auto prefetch = [&](int t0) __attribute__((always_inline)) {
             const int p = lane / 8, c0 = c_lo + kLead + t0 + (lane % 8) * 8;  // lane -> pair lane/8, eight columns
@@ -299,9 +359,13 @@ score_long_kernel(const LongArgs args) {
             for (int x = 0; x < 8; ++x) pre_base[x] = (c0 + x < F) ? src[c0 + x] : (unsigned char)0;
             const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;   // lane -> group lane/16, four columns
             pre_brow_valid = s > 0 && col + 4 <= args.row_dwords;
-            if (pre_brow_valid)         // L2-served load: the same addresses were read two strips ago and rewritten since
+            if (pre_brow_valid) {       // L2-served load: the same addresses were read two strips ago and rewritten since
                 pre_brow = __builtin_nontemporal_load(
-                    reinterpret_cast<const u32x4 *>(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + col));
+                    reinterpret_cast<const u32x4 *>(brow_prev + brow_slot_of(g, half, 0) * args.row_dwords + col));
+                if constexpr (AFFINE)
+                    pre_frow = __builtin_nontemporal_load(
+                        reinterpret_cast<const u32x4 *>(brow_prev + brow_slot_of(g, half, 1) * args.row_dwords + col));
+            }
         };
         auto commit = [&](int t0) __attribute__((always_inline)) {
             {
@@ -323,10 +387,23 @@ score_long_kernel(const LongArgs args) {
                     v.w = (col + 3 >= p_lo && col + 3 <= p_hi) ? pre_brow.w : 0u;
                 }
                 *reinterpret_cast<uint4 *>(ring_in + g * kRing + (col & (kRing - 1))) = v;
+                if constexpr (AFFINE) {                                  // F of the row above: the border value where there is none
+                    uint4 vf = make_uint4(border_f_bits, border_f_bits, border_f_bits, border_f_bits);
+                    if (pre_brow_valid) {
+                        vf.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? pre_frow.x : border_f_bits;
+                        vf.y = (col + 1 >= p_lo && col + 1 <= p_hi) ? pre_frow.y : border_f_bits;
+                        vf.z = (col + 2 >= p_lo && col + 2 <= p_hi) ? pre_frow.z : border_f_bits;
+                        vf.w = (col + 3 >= p_lo && col + 3 <= p_hi) ? pre_frow.w : border_f_bits;
+                    }
+                    *reinterpret_cast<uint4 *>(ring_in_f + g * kRing + (col & (kRing - 1))) = vf;
+                }
                 if (t0 >= 2 * kPhase && s + 1 < args.strips) {           // drain what lane G-1 finished two phases ago
                     const int oc = col - kLead - 2 * kPhase;
-                    *reinterpret_cast<uint4 *>(brow_cur + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + oc) =
+                    *reinterpret_cast<uint4 *>(brow_cur + brow_slot_of(g, half, 0) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
+                    if constexpr (AFFINE)
+                        *reinterpret_cast<uint4 *>(brow_cur + brow_slot_of(g, half, 1) * args.row_dwords + oc) =
+                            *reinterpret_cast<const uint4 *>(ring_out_f + g * kRing + (oc & (kRing - 1)));
                 }
             }
         };
@@ -340,10 +417,13 @@ score_long_kernel(const LongArgs args) {
                 (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
             if (lane < geo::kGroups * kLead) {
                 const int g = lane / kLead, bc = c_lo + (lane % kLead);
-                unsigned v = 0u;
-                if (s > 0 && bc < args.row_dwords && bc >= p_lo && bc <= p_hi)
-                    v = __builtin_nontemporal_load(brow_prev + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + bc);
+                unsigned v = 0u, vf = border_f_bits;
+                if (s > 0 && bc < args.row_dwords && bc >= p_lo && bc <= p_hi) {
+                    v = __builtin_nontemporal_load(brow_prev + brow_slot_of(g, half, 0) * args.row_dwords + bc);
+                    if constexpr (AFFINE) vf = __builtin_nontemporal_load(brow_prev + brow_slot_of(g, half, 1) * args.row_dwords + bc);
+                }
                 ring_in[g * kRing + (bc & (kRing - 1))] = v;
+                if constexpr (AFFINE) ring_in_f[g * kRing + (bc & (kRing - 1))] = vf;
             }
         }
         prefetch(0);
@@ -386,9 +466,13 @@ score_long_kernel(const LongArgs args) {
             const int g = lane / 16;
             for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
                 const int oc = c_lo + ph * kPhase + (lane % 16) * 4;
-                if (oc + 4 <= args.row_dwords)
-                    *reinterpret_cast<uint4 *>(brow_cur + (WIDE ? (pp0 + g) * 2 + half : (pp0 + g)) * args.row_dwords + oc) =
+                if (oc + 4 <= args.row_dwords) {
+                    *reinterpret_cast<uint4 *>(brow_cur + brow_slot_of(g, half, 0) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
+                    if constexpr (AFFINE)
+                        *reinterpret_cast<uint4 *>(brow_cur + brow_slot_of(g, half, 1) * args.row_dwords + oc) =
+                            *reinterpret_cast<const uint4 *>(ring_out_f + g * kRing + (oc & (kRing - 1)));
+                }
             }
         }
         if (ALG == kAlgNW) {                    // every lane froze at the last column: this strip's rows
