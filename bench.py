@@ -356,15 +356,32 @@ def abi_leg(reads, refs, threads, devices=1):
         # "fresh": rows of earlier calls are still alive, as in the reference's timing loop, which leaks them
         # (main.cpp:280-285) -- every call gets memory the process has never touched.  "recycled": the host
         # destroyed the previous call's Alignment array first (what a host that consumes its results does).
+        # the floor the contract sets on this host, no plugin involved: 2n rows allocated and written by `threads` threads
+        floor_fresh, _ = host.alloc_probe(n, R + F, threads)
         total, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=False)
         fresh = min(per_call[1:])
         phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
         out["compute_alignments_sw"] = {"ms_fresh_rows": round(fresh * 1e3, 2), "gcups_fresh_rows": round(n * R * F / fresh / 1e9, 1),
+                                        "ms_2n_fresh_new_rows_alone": round(floor_fresh * 1e3, 2),
                                         "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
         total, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=True)
         recycled = min(per_call[1:])
         out["compute_alignments_sw"].update({"ms_recycled_rows": round(recycled * 1e3, 2),
                                              "gcups_recycled_rows": round(n * R * F / recycled / 1e9, 1)})
+    # the same call through the flat C entry point (include/valign_hip.h: valign_hip_align_host): caller-provided
+    # contiguous result buffers instead of 2n heap blocks -- what an FFI binding that does not need Alignment objects uses
+    from versalignlib_amd import hipkernel
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **AFFINE))
+    eng.align_host(0, h_reads[:65536], h_refs[:65536], threads=threads)
+    eng.align_host(0, h_reads, h_refs, threads=threads)
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        eng.align_host(0, h_reads, h_refs, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+    eng.close()
+    out["compute_alignments_sw_flat_buffers"] = {"ms": round(best * 1e3, 2), "gcups": round(n * R * F / best / 1e9, 1),
+                                                 "note": "includes numpy's allocation of the 1.3 KB/pair result arrays"}
     # the reference host's own protocol on BASELINE configs[0]: 1,000 pairs of 64 x 128, linear gaps,
     # 100 back-to-back compute_alignments(SW) calls, microseconds per call (main.cpp:66-69, 268-292)
     r1, f1 = synth.make_pairs(1000, 64, 128, seed=1)

@@ -91,6 +91,12 @@ int vh_score_scattered(vh_plugin *p, int opt, int n, const uint8_t *reads,
 int vh_time_calls(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs, int reps,
                   int align, int free_between, double *seconds_out);
 
+/* What the ABI's result contract costs ANY backend on this host: `threads` threads allocate 2 * n rows of
+ * row_bytes with operator new[] (the caller's ~Alignment delete[]s them, include/AlignmentKernel.h:20-23) and
+ * write every byte once -- no plugin involved.  seconds_out[0] = the allocation + fill, seconds_out[1] = the
+ * delete[]s by the calling thread.  A measuring aid for bench.py's `abi` object.                            */
+int vh_alloc_probe(int n, int row_bytes, int threads, double *seconds_out);
+
 /* delete_alignment_kernel + dlclose + free.                                          */
 void vh_close(vh_plugin *p);
 

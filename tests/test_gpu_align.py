@@ -337,6 +337,11 @@ def test_in_plugin_device_shards():
     exp_scores = cpu_ref.score(host.SW, reads, refs, threads=8)
     exp = cpu_ref.align(host.NW, reads, refs, threads=8)
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=6, hip_devices=3) as hip:
+        # on a node with several GPUs the shards sit on DISTINCT devices (this is where that is exercised on real
+        # hardware); a one-GPU box folds them onto device 0
+        visible = hipkernel.lib().valign_hip_device_count()
+        want = ", ".join(str(d % visible) for d in range(3))
+        assert "shards on devices [%s] of %d visible" % (want, visible) in hip.drain_log()
         assert np.array_equal(hip.score_alignments(host.SW, reads, refs), exp_scores)
         _assert_same(hip.compute_alignments(host.NW, reads, refs, normalise=False), exp, "3 shards")
         assert np.array_equal(hip.score_alignments(host.SW, reads[:2], refs[:2]), exp_scores[:2])     # fewer pairs than shards

@@ -41,8 +41,6 @@ def test_long_shapes_select_the_long_path(R, F, n):
             got = hip.score_alignments(opt, reads, refs)
             assert np.array_equal(got, cpu_ref.score(opt, reads, refs, threads=8))
         assert '"long_mode": 1' in hip.drain_log()
-        with pytest.raises(host.PluginError, match="one register sweep"):
-            hip.compute_alignments(0, reads, refs)
 
 
 def test_config5_shape_10k_by_10k():
@@ -287,3 +285,58 @@ def test_banded_affine(band):
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band, **keys) as hip:
         got = hip.score_alignments(0, reads, refs)
     assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, band, sc, threads=8, block_rows=block_rows, col_align=col_align, affine=True))
+
+
+def _same_alignments(got, exp, what):
+    rows, idx = got
+    erows, eidx = exp
+    bad = np.nonzero((idx != eidx).any(axis=1))[0]
+    assert bad.size == 0, (what, "idx", bad[:5], idx[bad[:3]], eidx[bad[:3]])
+    bad = np.nonzero((rows != erows).any(axis=(1, 2)))[0]
+    assert bad.size == 0, (what, "rows", bad[:5])
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(3000, 3500, 9, 1), (2500, 700, 11, 2), (2049, 300, 7, 3), (5000, 4000, 4, 4), (4100, 9000, 3, 5)])
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_alignments_of_long_reads(R, F, n, seed, gaps):
+    """compute_alignments beyond one register sweep (read_length > 2048): row strips with boundary rows through
+    HBM, one pointer region per strip, the traceback crossing strips -- rows and coordinates of both modes against
+    the oracle (the reference computes alignments for any shape its short coordinates allow,
+    DefaultKernel.cpp:391-456).  Odd pair counts leave a wave half empty."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.15, short_frac=0.25,
+                                   lowercase_frac=0.05, junk_frac=0.03)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1], num_threads=4) as hip:
+        for opt in (host.SW, host.NW):
+            if opt == host.NW and (R + 1) * min(gaps) < -32000:
+                continue
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            _same_alignments(got, cpu_ref.align(opt, reads, refs, sc, threads=8), (R, F, opt))
+
+
+def test_alignments_config5_shape():
+    """10 kbp x 10 kbp alignments of both modes (five strips of 2048 rows): with the default scores the cells stay
+    inside int16 (column 0 of the NW variant reaches -30 003); gap scores of -4 would leave it, which is refused
+    instead of wrapping like the reference's shorts do."""
+    R = F = 10000
+    n = 3
+    reads, refs = synth.make_pairs(n, R, F, seed=61, sub_rate=0.1, indel_rate=0.01, n_run_frac=0.3, short_frac=0.34)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as hip:
+        for opt in (host.SW, host.NW):
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            _same_alignments(got, cpu_ref.align(opt, reads, refs, threads=8), ("10k", opt))
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, score_gap_read=-4, score_gap_ref=-4) as hip:
+        with pytest.raises(host.PluginError, match="int16 range"):
+            hip.compute_alignments(host.NW, reads, refs)
+
+
+def test_long_alignments_refuse_what_they_do_not_implement():
+    R, F = 3000, 500
+    reads, refs = synth.make_pairs(2, R, F, seed=5)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5,
+                     score_gap_extend_ref=-1) as hip:
+        with pytest.raises(host.PluginError, match="linear gap model"):
+            hip.compute_alignments(host.SW, reads, refs)
+    with host.Plugin(build.HIP_PLUGIN, R, F, traceback_policy=1) as hip:
+        with pytest.raises(host.PluginError, match="default tie-breaks"):
+            hip.compute_alignments(host.SW, reads, refs)

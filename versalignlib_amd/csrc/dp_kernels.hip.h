@@ -59,6 +59,7 @@ constexpr int kCodePad = 72;          // columns of zero-slab codes before colum
 constexpr short kNegInf = -16384;   // "minus infinity" of the affine NW borders (oracle: NEG_INF)
 
 constexpr int kMaxScoreGroups = 16;
+constexpr int kOneSweep = 0x7FFFFFFF;      // wave_setup: the sweep covers the whole read (padding rows on top)
 
 struct ScoreArgs {
     const uint8_t *reads;     // n * R bytes, pair-major
@@ -221,11 +222,14 @@ template <int G, int K, bool FIND_BAD>
 __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F,
                                            int prof_area, int refc_stride, int wave_lds, short match,
                                            short mismatch, WaveTables &w, bool bad_is_non_acgt = false,
-                                           unsigned block = blockIdx.x, short zero_score = 0) {
+                                           unsigned block = blockIdx.x, short zero_score = 0,
+                                           int strip_row0 = kOneSweep) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const int pad_rows = geo::kRows - R;
+    // read position of padded row 0 of this sweep: -(padding rows) when one sweep covers the read; a row strip
+    // of a longer read (strip_kernels.hip.h) starts wherever it starts, rows outside [0, R) are padding
+    const int row0 = strip_row0 == kOneSweep ? R - geo::kRows : strip_row0;
 
     unsigned char *lds = valign_smem + (size_t)wave * wave_lds;
     unsigned char *prof = lds;
@@ -249,7 +253,8 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             const int idx = lane + kWave * i;
             const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
             const int ps = p > last ? last : p;
-            rd[i] = rr >= pad_rows ? reads[(pair0 + ps) * R + (rr - pad_rows)] : (unsigned char)0;
+            const int pos = row0 + rr;
+            rd[i] = (pos >= 0 && pos < R) ? reads[(pair0 + ps) * R + pos] : (unsigned char)0;
         }
         // ---- raw refs into the (not yet built) profile area ----
         ref_lo = pair0 * F;
@@ -304,9 +309,11 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
         for (int i = 0; i < 2 * K; ++i) {
             const int idx = lane + kWave * i;
             const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
-            const int a = rr >= pad_rows ? base_class(rd[i]) : 0;
-            if (FIND_BAD && rr >= pad_rows && (a == 0 || (bad_is_non_acgt && a == 5)))
-                atomicMin(&first_bad[2 * p], rr - pad_rows);
+            const int pos = row0 + rr;
+            const bool in_read = pos >= 0 && pos < R;
+            const int a = in_read ? base_class(rd[i]) : 0;
+            if (FIND_BAD && in_read && (a == 0 || (bad_is_non_acgt && a == 5)))
+                atomicMin(&first_bad[2 * p], pos);
             const bool valid = a >= 1 && a <= 4;
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll

@@ -26,6 +26,7 @@
 
 #include "kernel_instances.hip.h"
 #include "long_kernels.hip.h"
+#include "strip_kernels.hip.h"
 
 namespace valign {
 
@@ -121,6 +122,20 @@ static const void *const kLongKernels[2][2][2] = {     // [alg][gap_read == gap_
      {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true>}},
     {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true>},
      {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, true>}}};
+
+// compute_alignments for reads beyond one register sweep (strip_kernels.hip.h): a wave per pair-of-pairs, K rows per lane
+struct StripGeometry {
+    int K;
+    WaveLds (*lds)(int R, int F);
+    const void *kernel[2];
+};
+static const StripGeometry kStripGeometries[] = {
+    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}},
+    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}},
+    {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>}},
+    {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>}},
+    {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>}},
+};
 
 struct LaunchPlan {
     bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
@@ -639,13 +654,14 @@ public:
                       short *d_idx, hipStream_t stream) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;
-        if (plan_.long_mode)
-            throw std::runtime_error("compute_alignments needs the pair to fit one register sweep (read_length <= 2048, "
-                                     "reference resident in LDS); this shape only supports score_alignments");
         check_int16_range(alg);
         if (alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000))
             throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
+        if (plan_.long_mode) {
+            align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
+            return;
+        }
         const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
         // affine gaps with the traceback information tagged into the cells (4-bit codes, 4-step blocks)
         const bool affine_tagged = sc_.affine && !sse_policy_ && !no_tag_ && affine_tagged_range_ok(alg);
@@ -705,7 +721,7 @@ public:
             hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(plan_.waves_per_block * kWave), fargs,
                                       (size_t)block_lds, stream),
                       "hipLaunchKernel(align_fill_kernel)");
-            TraceArgs t;
+            TraceArgs t{};
             t.reads = f.reads;
             t.refs = f.refs;
             t.ptr = d_ptr_;
@@ -734,6 +750,129 @@ public:
             void *targs[] = {&t};
             hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
                                       targs, 0, stream),
+                      "hipLaunchKernel(traceback_kernel)");
+        }
+    }
+
+    // Reads beyond one register sweep: row strips of 64 * K rows, one launch per strip in stream order, boundary
+    // rows ping-pong through HBM, one pointer region per strip, then the same traceback kernel (strip_kernels.hip.h).
+    // Linear gaps, Default tie-breaks, int16 cells (the reference's; where they would wrap the call is refused by
+    // check_int16_range above instead of wrapping silently).
+    void align_strips_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
+                             short *d_idx, hipStream_t stream) {
+        if (sc_.affine || sse_policy_)
+            throw std::runtime_error("compute_alignments for read_length > 2048 (row strips) implements the linear gap model "
+                                     "with the default tie-breaks only");
+        const StripGeometry *geo = nullptr;
+        WaveLds lds{};
+        for (int budget : {kMaxBlockLds / 2, kMaxBlockLds}) {            // two waves per CU if possible
+            for (const StripGeometry &g : kStripGeometries) {
+                const WaveLds w = g.lds(64 * g.K, F_);
+                if (w.total <= budget && !geo) {
+                    geo = &g;
+                    lds = w;
+                }
+            }
+            if (geo) break;
+        }
+        if (!geo) throw std::runtime_error("ref_length " + std::to_string(F_) + " does not fit the LDS of one CU");
+        const int K = geo->K, rows = 64 * K, AL = R_ + F_;
+        const int strips = std::max(1, (R_ + rows - 1) / rows), pad_total = strips * rows - R_;
+        const int blocks8 = (F_ + 63 + 7) / 8;
+        const int row_dwords = ((F_ + 71) / 64 + 2) * 64;
+        const size_t strip_words = (size_t)blocks8 * 64 * K;                       // per wave (= pair-of-pairs) and strip
+        const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_dwords * 4;
+        size_t free_b = 0, total_b = 0;
+        hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
+        const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
+        long long chunk = std::max<long long>(2, (long long)(cap / bytes_per_pp) * 2);
+        chunk = std::min(chunk, (n + 1) / 2 * 2);
+        const long long waves = chunk / 2;
+        const size_t need = (size_t)waves * bytes_per_pp;
+        if (need > trace_bytes_ || chunk > trace_pairs_ || (size_t)2 * n * sizeof(int) > first_bad_bytes_) {
+            hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if (need > trace_bytes_) {
+                if (d_ptr_) (void)hipFree(d_ptr_);
+                d_ptr_ = nullptr;
+                trace_bytes_ = 0;
+                hip_check(hipMalloc((void **)&d_ptr_, need), "hipMalloc(pointer scratch)");
+                trace_bytes_ = need;
+            }
+            if (chunk > trace_pairs_) {
+                if (d_ends_) (void)hipFree(d_ends_);
+                d_ends_ = nullptr;
+                trace_pairs_ = 0;
+                hip_check(hipMalloc((void **)&d_ends_, sizeof(EndCell) * (size_t)chunk), "hipMalloc(end cells)");
+                trace_pairs_ = chunk;
+            }
+            if ((size_t)2 * n * sizeof(int) > first_bad_bytes_) {
+                if (d_first_bad_) (void)hipFree(d_first_bad_);
+                d_first_bad_ = nullptr;
+                first_bad_bytes_ = 0;
+                hip_check(hipMalloc((void **)&d_first_bad_, (size_t)2 * n * sizeof(int)), "hipMalloc(first invalid positions)");
+                first_bad_bytes_ = (size_t)2 * n * sizeof(int);
+            }
+        }
+        unsigned *boundary = d_ptr_ + (size_t)waves * strip_words * strips;        // two rows per pair-of-pairs behind the pointers
+        hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
+        hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_);
+        hip_check(hipGetLastError(), "hipLaunchKernel(first_invalid_kernel)");
+        const void *fn = geo->kernel[alg];
+        if (lds.total > kDefaultBlockLds)
+            hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds.total),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        for (long long begin = 0; begin < n; begin += chunk) {
+            const long long cnt = std::min(chunk, n - begin), cnt_waves = (cnt + 1) / 2;
+            for (int s = 0; s < strips; ++s) {
+                StripArgs a;
+                a.reads = d_reads + (size_t)begin * R_;
+                a.refs = d_refs + (size_t)begin * F_;
+                a.ptr = d_ptr_ + (size_t)s * cnt_waves * strip_words;
+                a.ends = d_ends_;
+                a.first_bad = d_first_bad_ + 2 * begin;
+                a.top = boundary + (size_t)((s & 1) ^ 1) * waves * row_dwords;
+                a.bottom = boundary + (size_t)(s & 1) * waves * row_dwords;
+                a.n = cnt;
+                a.R = R_;
+                a.F = F_;
+                a.prof_area = lds.prof_area;
+                a.refc_stride = lds.refc_stride;
+                a.wave_lds = lds.total;
+                a.blocks8 = blocks8;
+                a.strip = s;
+                a.strips = strips;
+                a.row_dwords = row_dwords;
+                a.match = (short)sc_.match;
+                a.mismatch = (short)sc_.mismatch;
+                a.gap_read = (short)sc_.gap_read;
+                a.gap_ref = (short)sc_.gap_ref;
+                void *kargs[] = {&a};
+                hip_check(hipLaunchKernel(fn, dim3((unsigned)cnt_waves), dim3(kWave), kargs, (size_t)lds.total, stream),
+                          "hipLaunchKernel(align_strip_kernel)");
+            }
+            TraceArgs t{};
+            t.reads = d_reads + (size_t)begin * R_;
+            t.refs = d_refs + (size_t)begin * F_;
+            t.ptr = d_ptr_;
+            t.ends = d_ends_;
+            t.rows = d_rows + (size_t)begin * 2 * AL;
+            t.idx = d_idx + (size_t)begin * 4;
+            t.n = cnt;
+            t.R = R_;
+            t.F = F_;
+            t.G = 64;
+            t.K = K;
+            t.pad_rows = pad_total;
+            t.blocks8 = blocks8;
+            t.alg = alg;
+            t.match = (short)sc_.match;
+            t.mismatch = (short)sc_.mismatch;
+            t.gap_read = (short)sc_.gap_read;
+            t.gap_ref = (short)sc_.gap_ref;
+            t.strip_rows = rows;
+            t.strip_words = (long long)(cnt_waves * strip_words);
+            void *targs[] = {&t};
+            hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), targs, 0, stream),
                       "hipLaunchKernel(traceback_kernel)");
         }
     }
@@ -992,6 +1131,9 @@ private:
         d_ends_ = nullptr;
         trace_pairs_ = 0;
         trace_bytes_ = 0;
+        if (d_first_bad_) (void)hipFree(d_first_bad_);
+        d_first_bad_ = nullptr;
+        first_bad_bytes_ = 0;
         for (int s = 0; s < kSlots; ++s) {
             if (h_rows_[s]) (void)hipHostFree(h_rows_[s]);
             if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
@@ -1360,6 +1502,8 @@ private:
     EndCell *d_ends_ = nullptr;
     long long trace_pairs_ = 0, align_staged_pairs_ = 0;
     size_t trace_bytes_ = 0;            // capacity of d_ptr_
+    int *d_first_bad_ = nullptr;        // row strips: first invalid read / ref position per pair
+    size_t first_bad_bytes_ = 0;
     uint8_t *h_rows_[kSlots] = {}, *d_rows_[kSlots] = {};
     short *h_idx_[kSlots] = {}, *d_idx_[kSlots] = {};
     hipEvent_t in_done_[kSlots] = {}, kernels_done_[kSlots] = {};   // align_host: H2D / kernels of the slot's chunk finished

@@ -88,6 +88,12 @@ public:
                 more_.back()->set_score_width(opt_param("score_width", 0));
                 more_.back()->set_ragged_batching(opt_param("ragged_batching", 0));
             }
+            if (shards > 1) {
+                std::string where = std::to_string(engine_->device());
+                for (auto &e : more_) where += ", " + std::to_string(e->device());
+                log_line(0, "hip_devices = " + std::to_string(shards) + ": shards on devices [" + where + "] of " +
+                                std::to_string(visible) + " visible");
+            }
             if (opt_param("host_malloc_tuning", 0) == 1) {
                 // compute_alignments must hand out 2n operator new[] blocks (the caller delete[]s them,
                 // include/AlignmentKernel.h:20-23).  At a million pairs glibc trims 1.4 GB back to the

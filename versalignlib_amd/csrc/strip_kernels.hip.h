@@ -1,0 +1,275 @@
+// strip_kernels.hip.h -- compute_alignments for reads that do not fit one register sweep (read_length > 2048).
+//
+// The reference computes alignments for every shape its 16-bit coordinates allow
+// (src/Kernels/default/DefaultKernel.cpp:391-456, pointer matrix :394-395).  Here the read is cut into ROW STRIPS
+// of 64 * K rows; each strip is one launch of align_strip_kernel -- the anti-diagonal register sweep of
+// align_fill_kernel (trace_kernels.hip.h) with a whole wave per pair-of-pairs -- and strips run one after the other
+// in stream order:
+//   * the bottom row of a strip (one packed dword per column: pair A low, pair B high) goes to an HBM boundary
+//     row and comes back as the row above the next strip.  Lane 0 needs one value per step: the wave loads 64
+//     columns at a time, coalesced, one per lane, 64 steps ahead, and each step broadcasts its column with
+//     v_readlane; the last lane's values are collected one lane per column and stored 64 at a time;
+//   * every strip streams its 2-bit pointers to its own region of the pointer scratch (layout of
+//     trace_kernels.hip.h, one region per strip), and traceback_kernel crosses from region to region;
+//   * what needs the whole pair -- the first invalid read / ref position of the NW variant's end-cell rule
+//     (DefaultKernel.cpp:307-315, 348-350) -- is computed up front by first_invalid_kernel; the Smith-Waterman end
+//     cell (row-major first maximum, :252-256) is the best of the strips' own, earlier strips winning ties.
+// Linear gap model and the Default kernel's tie-breaks (pointer by equality tests, as align_fill_kernel): the
+// tagged-cell kernels keep 4 x cell in int16, which long reads outgrow.
+#pragma once
+
+#include "trace_kernels.hip.h"
+
+namespace valign {
+
+struct StripArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    unsigned *ptr;              // pointer stream region of THIS strip
+    EndCell *ends;              // n; read-modify-write across strips (SW), written by the owning strip (NW)
+    const int *first_bad;       // n x 2: first invalid read / ref position (else R / F), first_invalid_kernel
+    const unsigned *top;        // boundary row above this strip: [pair-of-pairs][row_dwords] (unused for strip 0)
+    unsigned *bottom;           // boundary row below
+    long long n;
+    int R, F;
+    int prof_area, refc_stride, wave_lds;
+    int blocks8;                // 8-step blocks per lane
+    int strip, strips;
+    int row_dwords;             // dwords per boundary row: a multiple of 64, >= F + 135 (whole 64-column stores / loads)
+    short match, mismatch;
+    short gap_read, gap_ref;
+};
+
+#ifndef VALIGN_KERNEL_PART_TU
+// First position of each read / ref whose base class is 0 (else R / F): one wave per pair.
+__global__ void __launch_bounds__(64)
+first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F, int *out) {
+    const long long pair = blockIdx.x;
+    if (pair >= n) return;
+    const int lane = threadIdx.x;
+    int ir = R, jr = F;
+    for (int i = lane; i < R; i += kWave)
+        if (base_class(reads[pair * R + i]) == 0) {
+            ir = i;
+            break;
+        }
+    for (int j = lane; j < F; j += kWave)
+        if (base_class(refs[pair * F + j]) == 0) {
+            jr = j;
+            break;
+        }
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) {
+        const int oi = __shfl_xor(ir, d, kWave), oj = __shfl_xor(jr, d, kWave);
+        ir = oi < ir ? oi : ir;
+        jr = oj < jr ? oj : jr;
+    }
+    if (lane == 0) {
+        out[2 * pair] = ir;
+        out[2 * pair + 1] = jr;
+    }
+}
+#endif
+
+template <int K, int ALG>
+__global__ void __launch_bounds__(64)
+align_strip_kernel(const StripArgs args) {
+    constexpr int G = 64;
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x;
+    const int l = lane;
+    const int R = args.R;
+    const int pad_total = args.strips * geo::kRows - R;             // padding rows above row 0, all in strip 0
+    const int row0 = args.strip * geo::kRows - pad_total;           // read position of this strip's first row
+
+    WaveTables w;
+    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
+                                 args.wave_lds, args.match, args.mismatch, w, false, blockIdx.x, 0, row0))
+        return;
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    unsigned code_addr = lds_offset(w.refc) - 2 * l;
+
+    const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
+    const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
+    s16x2 one = pk(1), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(four), "+v"(fifteen));     // keep the packed forms (see align_fill_kernel)
+
+    int ir[2], jr[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const long long p = w.pair0 + (half > w.last ? w.last : half);
+        ir[half] = args.first_bad[2 * p];
+        jr[half] = args.first_bad[2 * p + 1];
+    }
+
+    s16x2 Hl[K], code[K], acc[K];
+    s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    short nw_seed[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const int pos = row0 + l * K + q;              // read position of the row (negative: padding)
+        short border = 0;
+        if (ALG == kAlgNW) border = pos < 0 ? (short)0 : (short)((pos + 1) * args.gap_ref);   // column 0 of the NW variant
+        Hl[q] = pk(border);
+        code[q] = pk(0);
+        acc[q] = pk(0);
+        if (ALG == kAlgSW) {
+            rb[q] = pk(0);
+            fc[q] = pk(0);
+        } else {
+            const bool ta = ir[0] >= 1 && pos == ir[0] - 1, tb = ir[1] >= 1 && pos == ir[1] - 1;
+            sel[q] = s16x2{(short)(ta ? 1 : 0), (short)(tb ? 1 : 0)};
+            if (ta) nw_seed[0] = border;
+            if (tb) nw_seed[1] = border;
+        }
+    }
+    if (ALG == kAlgNW) {
+        rb[0] = s16x2{nw_seed[0], nw_seed[1]};
+        fc[0] = pk((short)l);
+    }
+    s16x2 h_last = Hl[K - 1];
+    // the row above the strip at column -1 (diagonal neighbour of lane 0's first cell): column 0's border
+    s16x2 up0 = pk(0);
+    if (ALG == kAlgNW && l == 0 && row0 - 1 >= 0) up0 = pk((short)(row0 * args.gap_ref));
+    int j = -l;
+
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
+    const long long pp = w.pair0 / 2;
+    const unsigned *top = args.top + pp * args.row_dwords;
+    unsigned *bottom = args.bottom + pp * args.row_dwords;
+    const bool has_top = args.strip > 0, has_bottom = args.strip + 1 < args.strips;
+    // 64 columns of the row above per lane-register, fetched 64 steps ahead (row_dwords covers the reads)
+    unsigned top_cur = 0u, top_next = has_top ? top[lane] : 0u;
+    unsigned bot_acc = 0u;
+
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;   // whole 8-step blocks
+    for (int t = 0; t < steps; ++t) {
+        if ((t & 63) == 0) {
+            top_cur = top_next;
+            top_next = (has_top && t + 64 + lane < args.row_dwords) ? top[t + 64 + lane] : 0u;
+        }
+        const s16x2 diag0 = up0;
+        const unsigned above = (unsigned)__builtin_amdgcn_readlane((int)top_cur, t & 63);      // H(row above, column t)
+        // every lane takes part in the DPP move: a lane masked off by the select would be read as 0 by its neighbour
+        unsigned from_lane = from_prev_lane(as_u32(h_last));
+        asm volatile("" : "+v"(from_lane));
+        up0 = as_pk(l == 0 ? above : from_lane);
+        if ((unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            const s16x2 tt = pk((short)t);
+            s16x2 d[K], m[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                const s16x2 e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                m[q] = pk_max(d[q], e);
+            }
+            s16x2 h = up0, hs = pk(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 ug = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                h = pk_max(m[q], ug);
+                const s16x2 nu = pk_min_u(h - ug, one);
+                Hl[q] = h;
+                // back pointer: 0 if h == diag + S, else 1 if it came from above, else 2 (DIAG > UP > LEFT)
+                const s16x2 nd = pk_min_u(h - d[q], one);
+                code[q] = (s16x2)((u16x2)nd << (u16x2)nu);
+                if (ALG == kAlgSW) {
+                    const s16x2 changed = (rb[q] - h) >> fifteen;          // 0xFFFF where h beats the row best
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = pk_max(rb[q], h);
+                } else {
+                    hs = pk_mad_u(h, sel[q], hs);                          // picks the cell of the one tracked row
+                }
+            }
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = h;
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
+        if ((t & 7) == 7) finish_block<K>(ptr_lane, t >> 3, acc);
+        // bottom row of the strip: lane 63 finished column t - 63
+        if (has_bottom) {
+            const int col = t - (G - 1);
+            if (col >= 0) {
+                const int v = __builtin_amdgcn_readlane((int)as_u32(h_last), G - 1);
+                bot_acc = lane == (col & 63) ? (unsigned)v : bot_acc;
+                if ((col & 63) == 63 || t == steps - 1) bottom[(col & ~63) + lane] = bot_acc;
+            }
+        }
+        ++j;
+        code_addr += 2;
+    }
+
+    // ---- end cell ----
+    const int strip_pad = args.strip * geo::kRows;          // padded row of this strip's first row
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const long long pair = w.pair0 + half;
+        if constexpr (ALG == kAlgSW) {
+            int bv = 0, bq = 0, bcol = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int v = half ? rb[q].y : rb[q].x;
+                const int c = (half ? fc[q].y : fc[q].x) & 0xFFFF;
+                if (v > bv) {
+                    bv = v;
+                    bq = q;
+                    bcol = c;
+                }
+            }
+            unsigned key = ((unsigned)bv << 16) | (unsigned)(0xFFFF - (l * K + bq));     // larger value, then smaller row
+            unsigned kmax = key;
+#pragma unroll
+            for (int dd = G / 2; dd >= 1; dd >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)kmax, dd, kWave);
+                kmax = other > kmax ? other : kmax;
+            }
+            const int p = 0xFFFF - (int)(kmax & 0xFFFF);
+            const int win_lane = p / K;
+            const int col_t = __shfl(bcol, win_lane, kWave);
+            EndCell out;
+            out.pad = 0;
+            out.score = (short)(kmax >> 16);
+            out.read_pos = (short)(strip_pad + p - pad_total);
+            out.ref_pos = (short)(col_t - win_lane);
+            if (out.score <= 0) {
+                out.read_pos = 0;
+                out.ref_pos = 0;
+            }
+            if (l == 0 && pair < args.n) {
+                // row-major first maximum over the whole matrix: a later strip only wins with a larger value
+                if (args.strip == 0 || out.score > args.ends[pair].score) args.ends[pair] = out;
+            }
+        } else {
+            // the strip that holds the last valid read row writes the end cell (strip 0 when there is none)
+            const int i_end = ir[half] - 1;
+            const int owner = i_end >= 0 ? (i_end + pad_total) / geo::kRows : 0;
+            if (owner != args.strip) continue;
+            int arg_col = 0;
+            if (i_end >= 0) {
+                const int src_l = (i_end + pad_total - strip_pad) / K;
+                const int mine = ((half ? fc[0].y : fc[0].x) & 0xFFFF) - l;
+                arg_col = __shfl(mine, src_l, kWave);
+            }
+            const int last_ref = jr[half] - 1;
+            EndCell out;
+            out.pad = 0;
+            out.score = 0;
+            out.read_pos = (short)i_end;
+            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+            if (l == 0 && pair < args.n) args.ends[pair] = out;
+        }
+    }
+}
+
+}  // namespace valign

@@ -1132,6 +1132,8 @@ struct TraceArgs {
                               // 2: 4-bit codes of align_fill_affine_tag_kernel, K words per 4-step block
     short match, mismatch, gap_read, gap_ref;
     short open_read, ext_read, open_ref, ext_ref;
+    int strip_rows;           // > 0: the read was swept in row strips of this many padded rows (strip_kernels.hip.h),
+    long long strip_words;    //      each with its own region of the pointer stream, this many dwords apart
 };
 
 typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
@@ -1154,7 +1156,8 @@ traceback_kernel(const TraceArgs a) {
     // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
     const int ppw = 2 * (kWave / G);
     const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
-    const long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
+    long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
+    if (a.strip_rows > 0) ptr_words += (long long)((R + a.pad_rows) / a.strip_rows - 1) * a.strip_words;   // ... of the last strip
     const int half_shift = (int)(pair & 1) * 16;
 
     int i = e.read_pos, j = e.ref_pos, h = e.score;
@@ -1216,10 +1219,16 @@ traceback_kernel(const TraceArgs a) {
             move = 1;                                   // column 0 of the NW variant: UP all the way
             state = 0;
         } else {
-            const int p = i + a.pad_rows;
+            int p = i + a.pad_rows;
+            long long region = 0;
+            if (a.strip_rows > 0) {                     // row strips: each has its own pointer region
+                const int strip = p / a.strip_rows;
+                p -= strip * a.strip_rows;
+                region = strip * a.strip_words;
+            }
             const int l = p / K, q = p - l * K;
             const int t = j + l;
-            const long long wi = ((long long)(a.tagged == 2 ? (t >> 2) : (t >> 3)) * kWave + l) * wpb + q;
+            const long long wi = region + ((long long)(a.tagged == 2 ? (t >> 2) : (t >> 3)) * kWave + l) * wpb + q;
             if (a.tagged == 2) {
                 const int f4 = code_at(wi, t);          // [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
                 if (state == 0) {
@@ -1292,6 +1301,7 @@ traceback_kernel(const TraceArgs a) {
         row_read[k + 1 + x] = (uint8_t)(out_r >> (8 * x));
         row_ref[k + 1 + x] = (uint8_t)(out_f >> (8 * x));
     }
+
     short *out = a.idx + pair * 4;
     out[0] = (short)(k + 1);
     out[1] = (short)(AL - 1);

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -268,6 +269,28 @@ int vh_align(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *
 }
 
 double vh_last_call_seconds(vh_plugin *p) { return p ? p->last_call_seconds : 0.0; }
+
+int vh_alloc_probe(int n, int row_bytes, int threads, double *seconds_out) {
+    if (n < 0 || row_bytes < 1 || threads < 1 || !seconds_out) return fail("bad argument");
+    std::vector<char *> rows((size_t)2 * n);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const size_t lo = (size_t)2 * n * t / threads, hi = (size_t)2 * n * (t + 1) / threads;
+            for (size_t i = lo; i < hi; ++i) {
+                rows[i] = new char[row_bytes];
+                memset(rows[i], (int)(i & 0x7F), (size_t)row_bytes);
+            }
+        });
+    for (auto &th : pool) th.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    for (char *r : rows) delete[] r;
+    const auto t2 = std::chrono::steady_clock::now();
+    seconds_out[0] = std::chrono::duration<double>(t1 - t0).count();
+    seconds_out[1] = std::chrono::duration<double>(t2 - t1).count();
+    return 0;
+}
 
 int vh_time_calls(vh_plugin *p, int opt, int n, const uint8_t *reads, const uint8_t *refs, int reps,
                   int align, int free_between, double *seconds_out) {

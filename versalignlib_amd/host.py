@@ -41,6 +41,7 @@ def lib():
         L.vh_align.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, u8p, i16p, ctypes.c_int]
         L.vh_time_calls.argtypes = [vp, ctypes.c_int, ctypes.c_int, u8p, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_double)]
+        L.vh_alloc_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.vh_last_call_seconds.restype = ctypes.c_double
         L.vh_last_call_seconds.argtypes = [vp]
         L.vh_close.restype = None
@@ -191,6 +192,15 @@ class Plugin:
             self.close()
         except Exception:
             pass
+
+
+def alloc_probe(n, row_bytes, threads):
+    """Seconds (allocate + fill, free) of 2 * n operator new[] rows of row_bytes on `threads` threads: what the
+    ABI's result contract costs any backend on this host (include/AlignmentKernel.h:20-23)."""
+    out = (ctypes.c_double * 2)()
+    if lib().vh_alloc_probe(int(n), int(row_bytes), int(threads), out) != 0:
+        raise PluginError(_err())
+    return out[0], out[1]
 
 
 def parse_fasta(path):
