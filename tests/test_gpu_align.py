@@ -378,3 +378,28 @@ def test_pointer_scratch_follows_the_widest_stream_of_an_engine(aff, order):
         _assert_same((rows.cpu().numpy(), idx.cpu().numpy()), exp, (aff, opt))
     assert bool((canary == 0x5A).all())
     eng.close()
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(64, 128, 1000, 1), (12, 20, 333, 2), (33, 70, 257, 3), (100, 37, 129, 4), (16, 16, 65, 5),
+                                         (1, 1, 5, 6), (128, 300, 77, 7), (150, 200, 50, 8), (250, 120, 31, 9)])
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_fused_small_batch_kernel(monkeypatch, R, F, n, seed, gaps):
+    """Small compute_alignments calls run fill + traceback in ONE launch with the pointer stream in LDS
+    (align_fill_tag_kernel<..., FUSED>): same alignments as the oracle and as the three-kernel path
+    (VALIGN_HIP_NO_FUSED), odd pair counts and half-empty waves included."""
+    reads, refs = _data(R, F, n, seed)
+    sc = hipkernel.Scoring.make(2, -1, gaps[0], gaps[1])
+    osc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    eng = hipkernel.Engine(R, F, sc)
+    monkeypatch.setenv("VALIGN_HIP_NO_FUSED", "1")
+    plain = hipkernel.Engine(R, F, sc)
+    monkeypatch.delenv("VALIGN_HIP_NO_FUSED")
+    for opt in (host.SW, host.NW):
+        exp = cpu_ref.align(opt, reads, refs, osc, threads=8)
+        got = eng.align_host(opt, reads, refs, threads=2)
+        assert eng.describe(opt, n)["direct_call"] == 2
+        _assert_same(got, exp, ("fused", opt))
+        _assert_same(plain.align_host(opt, reads, refs, threads=2), exp, ("three kernels", opt))
+        assert plain.describe(opt, n)["direct_call"] == 1
+    eng.close()
+    plain.close()

@@ -285,7 +285,7 @@ def test_small_calls_run_on_the_pinned_staging_directly(monkeypatch):
             assert eng.describe(opt, n)["direct_call"] == (1 if direct else 0)
             rows, idx = eng.align_host(opt, reads, refs, threads=2)
             assert np.array_equal(idx, exp_rows[opt][1]) and np.array_equal(rows, exp_rows[opt][0])
-            assert eng.describe(opt, n)["direct_call"] == (1 if direct else 0)
+            assert eng.describe(opt, n)["direct_call"] == (2 if direct else 0)       # 2: fill + traceback in ONE launch
         # a large call on the same engine goes through the pipeline again
         big_r, big_f = np.tile(reads, (40, 1)), np.tile(refs, (40, 1))
         assert np.array_equal(eng.score_host(0, big_r, big_f, threads=4), np.tile(exp[0], 40))

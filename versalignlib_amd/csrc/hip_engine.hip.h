@@ -137,6 +137,23 @@ static const StripGeometry kStripGeometries[] = {
     {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>}},
 };
 
+// Small batches: fill + traceback in one launch, pointer stream in LDS (align_fill_tag_kernel<..., FUSED>)
+struct FusedGeometry {
+    int G, K;
+    WaveLds (*lds)(int R, int F);
+    int (*total)(int wave_lds, int R, int F, int blocks8);
+    const void *kernel[2];
+};
+template <int G, int K>
+constexpr FusedGeometry make_fused() {
+    return FusedGeometry{G, K, &wave_lds<G, K>,
+                         [](int wl, int R, int F, int b8) { return fused_lds<G, K>(wl, R, F, b8).total; },
+                         {(const void *)&align_fill_tag_kernel<G, K, kAlgSW, false, false, true>,
+                          (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, false, true>}};
+}
+static const FusedGeometry kFusedGeometries[] = {make_fused<8, 4>(), make_fused<16, 4>(), make_fused<16, 8>(),
+                                                 make_fused<16, 10>(), make_fused<32, 8>()};
+
 struct LaunchPlan {
     bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
     const Geometry *geo = nullptr;
@@ -239,7 +256,7 @@ public:
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
         double classify_ms = 0;                              // part of gather_ms: trimmed lengths + binning
-        int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly
+        int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly; 2: ... in one fused launch
     };
 
     Engine(int device, int R, int F, const Scoring &sc, int force_g, int force_k)
@@ -754,6 +771,64 @@ public:
         }
     }
 
+    // Fill + traceback of a small batch in one launch (linear gaps, default tie-breaks, tagged cells): false when the
+    // shape / scoring has no fused kernel (the caller takes the three-kernel path).
+    bool align_fused(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows, short *d_idx,
+                     hipStream_t stream) {
+        if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg)) return false;
+        try {
+            check_int16_range(alg);
+        } catch (const std::runtime_error &) {
+            return false;                           // let the regular path raise its error
+        }
+        if (alg == kAlgNW && (long long)(R_ + 1) * std::min(sc_.gap_ref, 0) < -32000) return false;
+        const FusedGeometry *best = nullptr;
+        WaveLds best_lds{};
+        int best_total = 0, best_blocks = 0;
+        double best_cost = 0;
+        for (const FusedGeometry &g : kFusedGeometries) {
+            if (g.G * g.K < R_) continue;
+            const WaveLds w = g.lds(R_, F_);
+            const int blocks8 = (F_ + g.G - 1 + 7) / 8;
+            const int total = g.total(w.total, R_, F_, blocks8);
+            if (total > kMaxBlockLds - 8192) continue;
+            const double cost = (double)(F_ + g.G - 1) * (g.K * 9.0 + 7.0);         // single-wave latency
+            if (!best || cost < best_cost) {
+                best = &g;
+                best_lds = w;
+                best_total = total;
+                best_blocks = blocks8;
+                best_cost = cost;
+            }
+        }
+        if (!best) return false;
+        FillArgs f{};
+        f.reads = d_reads;
+        f.refs = d_refs;
+        f.n = n;
+        f.R = R_;
+        f.F = F_;
+        f.prof_area = best_lds.prof_area;
+        f.refc_stride = best_lds.refc_stride;
+        f.wave_lds = best_lds.total;
+        f.blocks8 = best_blocks;
+        f.match = (short)sc_.match;
+        f.mismatch = (short)sc_.mismatch;
+        f.gap_read = (short)sc_.gap_read;
+        f.gap_ref = (short)sc_.gap_ref;
+        f.out_rows = d_rows;
+        f.out_idx = d_idx;
+        const void *fn = best->kernel[alg];
+        if (best_total > kDefaultBlockLds)
+            hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, best_total),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        const long long ppw = 2 * (kWave / best->G);
+        void *fargs[] = {&f};
+        hip_check(hipLaunchKernel(fn, dim3((unsigned)((n + ppw - 1) / ppw)), dim3(kWave), fargs, (size_t)best_total, stream),
+                  "hipLaunchKernel(align_fill_tag_kernel, fused)");
+        return true;
+    }
+
     // Reads beyond one register sweep: row strips of 64 * K rows, one launch per strip in stream order, boundary
     // rows ping-pong through HBM, one pointer region per strip, then the same traceback kernel (strip_kernels.hip.h).
     // Linear gaps, Default tie-breaks, int16 cells (the reference's; where they would wrap the call is refused by
@@ -919,9 +994,20 @@ public:
             gather(reads, refs, n, h_reads_[0], h_refs_[0], threads);
             auto t1 = std::chrono::steady_clock::now();
             const size_t rows_bytes = ((size_t)n * 2 * AL + 15) / 16 * 16, all_bytes = rows_bytes + sizeof(short) * 4 * (size_t)n;
-            // (the slot's row buffer is sized for `chunk` >= 1024 pairs: rows + coordinates of n <= chunk pairs fit
-            // whenever 8 n <= 2 AL (chunk - n); else the coordinates use their own buffer and a second copy)
-            const bool one_copy = all_bytes <= (size_t)align_staged_pairs_ * 2 * AL;
+            if (align_fused(alg, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), dev_view(h_rows_[0]),
+                            (short *)(dev_view(h_rows_[0]) + rows_bytes), kernels)) {
+                // ONE launch: the wave that fills a pair's pointers (kept in LDS) walks it back and writes the rows
+                // straight into the pinned staging
+                hip_check(hipStreamSynchronize(kernels), "hipStreamSynchronize");
+                auto t2 = std::chrono::steady_clock::now();
+                scatter(alignments, n, h_rows_[0], (const short *)(h_rows_[0] + rows_bytes), threads);
+                host_stats_.gather_ms = ms_between(t0, t1);
+                host_stats_.wait_ms = ms_between(t1, t2);
+                host_stats_.drain_ms = ms_between(t2, std::chrono::steady_clock::now());
+                host_stats_.direct = 2;
+                return;
+            }
+            const bool one_copy = true;              // the slot's row buffers have room for the coordinates behind the rows
             short *d_idx = one_copy ? (short *)(d_rows_[0] + rows_bytes) : d_idx_[0];
             align_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), d_rows_[0], d_idx, kernels);
             if (one_copy) {
@@ -1180,9 +1266,11 @@ private:
             if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
             if (d_rows_[s]) (void)hipFree(d_rows_[s]);
             if (d_idx_[s]) (void)hipFree(d_idx_[s]);
-            hip_check(hipHostMalloc((void **)&h_rows_[s], std::max<size_t>((size_t)pairs * 2 * AL, 16), hipHostMallocDefault), "hipHostMalloc");
+            // (room for the coordinates behind the rows: small calls bring both back in one piece)
+            const size_t rows_cap = (size_t)pairs * 2 * AL + sizeof(short) * 4 * (size_t)pairs + 32;
+            hip_check(hipHostMalloc((void **)&h_rows_[s], rows_cap, hipHostMallocDefault), "hipHostMalloc");
             hip_check(hipHostMalloc((void **)&h_idx_[s], sizeof(short) * 4 * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
-            hip_check(hipMalloc((void **)&d_rows_[s], std::max<size_t>((size_t)pairs * 2 * AL, 16)), "hipMalloc");
+            hip_check(hipMalloc((void **)&d_rows_[s], rows_cap), "hipMalloc");
             hip_check(hipMalloc((void **)&d_idx_[s], sizeof(short) * 4 * (size_t)pairs), "hipMalloc");
         }
         align_staged_pairs_ = pairs;
@@ -1485,6 +1573,7 @@ private:
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
+    bool no_fused_ = getenv("VALIGN_HIP_NO_FUSED") != nullptr;   // tuning switch: small alignment calls as fill + traceback kernels
     std::string arch_;
     LaunchPlan plan_, latency_plan_;
     hipStream_t streams_[kSlots] = {};

@@ -45,6 +45,10 @@ struct FillArgs {
     short match, mismatch;
     short gap_read, gap_ref;
     short open_read, ext_read, open_ref, ext_ref;     // affine fill only
+    // fused small-batch kernel (align_fill_tag_kernel<..., FUSED>): where the finished alignments go -- no pointer
+    // scratch, no end cells, no second kernel
+    uint8_t *out_rows;        // n * 2 * (R+F), need not be zeroed
+    short *out_idx;           // n * 4
 };
 
 __device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
@@ -53,6 +57,216 @@ __device__ __forceinline__ s16x2 pk_min_u(s16x2 a, s16x2 b) {
 __device__ __forceinline__ s16x2 pk_mad_u(s16x2 a, s16x2 b, s16x2 c) {
     return (s16x2)((u16x2)a * (u16x2)b + (u16x2)c);
 }
+
+struct TraceArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    const unsigned *ptr;
+    const EndCell *ends;
+    uint8_t *rows;            // n * 2 * (R+F), pre-zeroed
+    short *idx;               // n * 4: readStart, readEnd, refStart, refEnd
+    long long n;
+    int R, F;
+    int G, K, pad_rows, blocks8;
+    int alg;
+    int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
+    int sse_policy;           // 1: stored states are 0 START, 1 UP, 2 LEFT, 3 DIAG (SSE/AVX kernel rules)
+    int tagged;               // 1: codes are the tags of align_fill_tag_kernel (2 DIAG, 1 UP, 0 LEFT);
+                              // 2: 4-bit codes of align_fill_affine_tag_kernel, K words per 4-step block
+    short match, mismatch, gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;
+    int strip_rows;           // > 0: the read was swept in row strips of this many padded rows (strip_kernels.hip.h),
+    long long strip_words;    //      each with its own region of the pointer stream, this many dwords apart
+};
+
+typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
+
+// The walk of ONE pair (one lane): from the end cell back along the stored pointers, writing the two right-justified
+// gapped rows and the four coordinates.  A chain of dependent loads, so what it costs is memory transactions:
+// pointer words are fetched 16 bytes (4 rows x 8 columns) at a time, read / ref bases 4 at a time, and the two
+// output rows are written as dwords.  `ptr_pair` is the first word of the pair's lane group in the pointer stream
+// (block 0), `ptr_words` the words from there to the end of the group's last block; `half` selects pair A / B of
+// the group.  Pointers may be global or LDS (generic): traceback_kernel walks the HBM scratch, the fused small-batch
+// kernel (align_fill_tag_kernel<..., FUSED>) the copy it keeps in LDS.
+template <bool BYTE_ROWS = false>      // BYTE_ROWS: rows in LDS -- one byte store per step, no dword at an odd address
+__device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *ptr_pair, long long ptr_words, int half,
+                                           const EndCell e, const uint8_t *read, const uint8_t *ref,
+                                           uint8_t *row_read, uint8_t *row_ref, short *out) {
+    const int R = a.R, F = a.F, AL = R + F, K = a.K;
+    const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;      // words per lane and block of steps
+    const int half_shift = half * 16;
+
+    int i = e.read_pos, j = e.ref_pos, h = e.score;
+    int k = AL - 2;
+    long long cached_at = -1;              // first word index held in c0..c3 (multiple of 4)
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int rd_at = -1, rf_at = -1;            // index / 4 of the cached read / ref dwords
+    unsigned rd_w = 0, rf_w = 0;
+    unsigned out_r = 0, out_f = 0;         // up to 4 pending output bytes per row, newest in the low byte
+    int pending = 0;
+    int state = 0;                         // affine only: 0 at H, 1 inside F (gap in the ref), 2 inside E
+
+    auto base_at = [](const uint8_t *seq, int len, int pos, int &at, unsigned &w) -> unsigned {
+        if ((pos >> 2) != at) {
+            at = pos >> 2;
+            const int b = at * 4;
+            if (b + 4 <= len) {
+                w = *reinterpret_cast<const u32_any_align *>(seq + b);
+            } else {
+                w = 0;
+                for (int x = 0; b + x < len; ++x) w |= (unsigned)seq[b + x] << (8 * x);
+            }
+        }
+        return (w >> (8 * (pos & 3))) & 0xFFu;
+    };
+    // 2-bit code of cell (i, j) from word `wi` of this pair-of-pairs, through a 4-word cache
+    auto code_at = [&](long long wi, int t) -> int {
+        const long long wb = wi & ~3ll;
+        if (wb != cached_at) {
+            cached_at = wb;
+            if (wb + 4 <= ptr_words) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
+                c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+            } else {
+                c0 = ptr_pair[wb];
+                c1 = wb + 1 < ptr_words ? ptr_pair[wb + 1] : 0u;
+                c2 = wb + 2 < ptr_words ? ptr_pair[wb + 2] : 0u;
+                c3 = 0u;
+            }
+        }
+        const int sel = (int)(wi & 3);
+        const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
+        if (a.tagged == 2) return (int)((word >> (half_shift + 4 * (3 - (t & 3)))) & 15u);
+        return (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
+    };
+
+    while (k >= 0) {
+        if (state == 0) {
+            if (a.sse_policy) {
+                if (i < 0 || (a.alg == kAlgSW && j < 0)) break;      // row 0 (and SW column 0): START
+            } else if (a.alg == kAlgSW) {
+                if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
+            } else {
+                if (i < 0) break;                       // row 0: START
+            }
+        }
+        int move;                                       // 0 DIAG, 1 UP (emit read, '-'), 2 LEFT
+        if (j < 0) {
+            move = 1;                                   // column 0 of the NW variant: UP all the way
+            state = 0;
+        } else {
+            int p = i + a.pad_rows;
+            long long region = 0;
+            if (a.strip_rows > 0) {                     // row strips: each has its own pointer region
+                const int strip = p / a.strip_rows;
+                p -= strip * a.strip_rows;
+                region = strip * a.strip_words;
+            }
+            const int l = p / K, q = p - l * K;
+            const int t = j + l;
+            const long long wi = region + ((long long)(a.tagged == 2 ? (t >> 2) : (t >> 3)) * kWave + l) * wpb + q;
+            if (a.tagged == 2) {
+                const int f4 = code_at(wi, t);          // [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
+                if (state == 0) {
+                    const int src = f4 >> 2;
+                    move = src == 2 ? 0 : (src == 1 ? 1 : 2);
+                    if (move != 0) {
+                        state = move;                   // nothing is emitted on entering a gap state
+                        continue;
+                    }
+                } else {
+                    move = state;
+                    if (state == 1) {
+                        if (f4 & 1) { h -= a.open_ref; state = 0; } else h -= a.ext_ref;
+                    } else {
+                        if (f4 & 2) { h -= a.open_read; state = 0; } else h -= a.ext_read;
+                    }
+                }
+            } else if (a.sse_policy) {
+                const int st = code_at(wi, t);          // 0 START, 1 UP, 2 LEFT, 3 DIAG
+                if (st == 0) break;
+                move = st == 3 ? 0 : st;
+            } else if (!a.affine) {
+                move = code_at(wi, t);
+                if (a.tagged) move = 2 - move;
+            } else if (state == 0) {
+                move = code_at(wi, t);                  // 0 DIAG, 1 enter F, 2 enter E
+                if (move != 0) {
+                    state = move;                       // nothing is emitted on entering a gap state
+                    continue;
+                }
+            } else {
+                const int bits = code_at(wi + K, t);    // bit0: F extended, bit1: E extended
+                move = state;
+                if (state == 1) {
+                    if (bits & 1) h -= a.ext_ref; else { h -= a.open_ref; state = 0; }
+                } else {
+                    if (bits & 2) h -= a.ext_read; else { h -= a.open_read; state = 0; }
+                }
+            }
+        }
+        unsigned br, bf;
+        if (move == 0) {
+            br = base_at(read, R, i, rd_at, rd_w);
+            bf = base_at(ref, F, j, rf_at, rf_w);
+            const int ca = base_class(br), cb = base_class(bf);
+            if (ca >= 1 && ca <= 4 && cb >= 1 && cb <= 4) h -= (ca == cb ? a.match : a.mismatch);
+            --i;
+            --j;
+        } else if (move == 1) {
+            br = base_at(read, R, i, rd_at, rd_w);
+            bf = '-';
+            if (!a.affine) h -= a.gap_ref;
+            --i;
+        } else {
+            br = '-';
+            bf = base_at(ref, F, j, rf_at, rf_w);
+            if (!a.affine) h -= a.gap_read;
+            --j;
+        }
+        if constexpr (BYTE_ROWS) {
+            row_read[k] = (uint8_t)br;
+            row_ref[k] = (uint8_t)bf;
+        } else {
+            out_r = (out_r << 8) | br;
+            out_f = (out_f << 8) | bf;
+            if (++pending == 4) {                       // bytes k .. k+3 of both rows, lowest address = newest
+                *reinterpret_cast<u32_any_align *>(row_read + k) = out_r;
+                *reinterpret_cast<u32_any_align *>(row_ref + k) = out_f;
+                pending = 0;
+            }
+        }
+        --k;
+    }
+    for (int x = 0; x < pending; ++x) {                 // k + 1 is the newest byte written
+        row_read[k + 1 + x] = (uint8_t)(out_r >> (8 * x));
+        row_ref[k + 1 + x] = (uint8_t)(out_f >> (8 * x));
+    }
+
+    out[0] = (short)(k + 1);
+    out[1] = (short)(AL - 1);
+    out[2] = (short)(k + 1);
+    out[3] = (short)(AL - 1);
+}
+
+#ifndef VALIGN_KERNEL_PART_TU      // not a template: defined once, in the plugin's main translation unit
+// One lane per pair over the HBM pointer scratch.
+__global__ void __launch_bounds__(256)
+traceback_kernel(const TraceArgs a) {
+    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n) return;
+    const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
+    const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;
+    // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
+    const int ppw = 2 * (kWave / G);
+    const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
+    long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
+    if (a.strip_rows > 0) ptr_words += (long long)((R + a.pad_rows) / a.strip_rows - 1) * a.strip_words;   // ... of the last strip
+    uint8_t *row_read = a.rows + pair * 2 * AL;
+    trace_walk(a, ptr_pair, ptr_words, (int)(pair & 1), a.ends[pair], a.reads + pair * R, a.refs + pair * F, row_read,
+               row_read + AL, a.idx + pair * 4);
+}
+#endif
 
 // POINTER STREAM LAYOUT: [wave][block of steps][lane of the wave][W words], W = K (2K for the two-stream affine
 // kernel).  What a wave stores for one block of steps -- 64 lanes x W dwords -- is ONE contiguous run (2.5 KB at
@@ -91,7 +305,8 @@ __device__ __forceinline__ void finish_block(unsigned *lane_base, long long bloc
 template <int G, int K, int ALG, int KEYBITS = 0, int NT = 1>
 __device__ __forceinline__ void write_end_cells(const FillArgs &args, const WaveTables &w, const s16x2 (&rb)[NT],
                                                 const s16x2 (&fc)[NT], const int (&ir)[2], const int (&jr)[2],
-                                                int pad_rows, int lane, int grp, int l, int score_shift = 0) {
+                                                int pad_rows, int lane, int grp, int l, int score_shift = 0,
+                                                EndCell *wave_ends = nullptr) {     // fused kernel: the wave's own table
     // ---- end cell of each of the two pairs of this group ----
     const int base_lane = lane - l;
 #pragma unroll
@@ -150,7 +365,10 @@ __device__ __forceinline__ void write_end_cells(const FillArgs &args, const Wave
             out.read_pos = (short)i_end;
             out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
         }
-        if (l == 0 && pair < args.n) args.ends[pair] = out;
+        if (l == 0 && pair < args.n) {
+            if (wave_ends) wave_ends[2 * grp + half] = out;
+            else args.ends[pair] = out;
+        }
     }
 }
 
@@ -349,10 +567,35 @@ align_fill_kernel(const FillArgs args) {
 // states then -- 3 on a valid diagonal (profile 4 * S + 3), 0 on an invalid one (profile 0), 2 on the
 // candidate from the left, 1 on the one from above, 0 on the SW floor -- cells are computed in the signed form
 // (the floor is an explicit maximum) and N counts as invalid for the NW end cell.
-template <int G, int K, int ALG, bool LANEKEY, bool SSE>
+// FUSED (small batches, one wave per block): the pointer stream stays in LDS, and the wave that filled it walks its
+// own pairs back right away and hands the finished rows out with coalesced stores -- ONE launch per call instead
+// of memset + fill + traceback (+ copy): what a small call costs is operations in the stream, ~25 us each, not
+// cells (the reference's benchmark is 100 such calls back to back, src/impl/main.cpp:278-287).  The sequences and
+// the result rows of the wave's pairs sit in LDS too, so the walk never waits for HBM (or, on the direct path,
+// for PCIe).  LDS per wave: fused_lds<G, K>().
+template <int G, int K>
+struct FusedLds {
+    int ptr, reads, refs, rows, ends, total;       // byte offsets behind the wave's tables
+};
+template <int G, int K>
+__host__ __device__ inline FusedLds<G, K> fused_lds(int wave_lds, int R, int F, int blocks8) {
+    using geo = Geo<G, K>;
+    auto up16 = [](int v) { return (v + 15) / 16 * 16; };
+    FusedLds<G, K> f;
+    f.ptr = up16(wave_lds);
+    f.reads = f.ptr + up16(blocks8 * kWave * K * 4);
+    f.refs = f.reads + up16(geo::kPairs * ((R + 3) & ~3));        // each sequence starts at a dword: the walk loads bases four at a time
+    f.rows = f.refs + up16(geo::kPairs * ((F + 3) & ~3));
+    f.ends = f.rows + up16(geo::kPairs * 2 * (R + F) + 4);
+    f.total = f.ends + up16(geo::kPairs * (int)sizeof(EndCell));
+    return f;
+}
+
+template <int G, int K, int ALG, bool LANEKEY, bool SSE, bool FUSED = false>
 __global__ void __launch_bounds__(256)
 align_fill_tag_kernel(const FillArgs args) {
     static_assert(!LANEKEY || ALG == kAlgSW, "the lane key replaces the Smith-Waterman row arg-max");
+    static_assert(!FUSED || (!LANEKEY && !SSE), "the fused kernel exists for the default tie-breaks");
     constexpr int kKeyBits = K <= 16 ? 4 : 5;
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -432,7 +675,11 @@ align_fill_tag_kernel(const FillArgs args) {
     s16x2 up0 = pk(0);
     int j = -l;
 
-    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
+    // FUSED: the wave's pointer stream lives in LDS behind its tables (same layout, wave 0 of its own little scratch)
+    const FusedLds<G, K> fused = fused_lds<G, K>(args.wave_lds, R, args.F, args.blocks8);
+    unsigned char *wave_smem = valign_smem + (size_t)(threadIdx.x / kWave) * (FUSED ? fused.total : args.wave_lds);
+    unsigned *ptr_lane = FUSED ? reinterpret_cast<unsigned *>(wave_smem + fused.ptr) + lane * K
+                               : pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
 
     // LDS fetches run one step ahead of the arithmetic, as in score_kernel: raw profile dwords of this
     // step in registers, rows of step t+1 and slab numbers of step t+2 requested now (every lane, every
@@ -558,8 +805,60 @@ align_fill_tag_kernel(const FillArgs args) {
     if (last_only) sweep(std::true_type{});
     else sweep(std::false_type{});
 
-    if constexpr (LANEKEY) write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
-    else write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
+    if constexpr (LANEKEY) {
+        write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
+    } else if constexpr (!FUSED) {
+        write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
+    } else {
+        // ---- fused: walk the wave's own pairs back through the LDS pointer stream, then hand the rows out ----
+        const int AL = R + args.F;
+        EndCell *wave_ends = reinterpret_cast<EndCell *>(wave_smem + fused.ends);
+        uint8_t *lds_reads = wave_smem + fused.reads, *lds_refs = wave_smem + fused.refs, *lds_rows = wave_smem + fused.rows;
+        write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2, wave_ends);
+        // the sequences of the wave's pairs and zeroed result rows (the profile build consumed the staged copy)
+        const int pairs_here = w.last + 1;
+        const int Rs = (R + 3) & ~3, Fs = (args.F + 3) & ~3;
+        for (int x = lane; x < pairs_here * R; x += kWave) lds_reads[(x / R) * Rs + x % R] = args.reads[w.pair0 * R + x];
+        for (int x = lane; x < pairs_here * args.F; x += kWave) lds_refs[(x / args.F) * Fs + x % args.F] = args.refs[w.pair0 * args.F + x];
+        for (int x = lane; x < (geo::kPairs * 2 * AL + 3) / 4; x += kWave) reinterpret_cast<unsigned *>(lds_rows)[x] = 0u;
+        __syncthreads();                       // one wave per block: the LDS writes above are visible to every lane
+        short my_idx[4] = {0, 0, 0, 0};
+        if (lane < pairs_here) {
+            TraceArgs t{};
+            t.R = R;
+            t.F = args.F;
+            t.G = G;
+            t.K = K;
+            t.pad_rows = pad_rows;
+            t.blocks8 = args.blocks8;
+            t.alg = ALG;
+            t.tagged = 1;
+            t.match = args.match;
+            t.mismatch = args.mismatch;
+            t.gap_read = args.gap_read;
+            t.gap_ref = args.gap_ref;
+            const unsigned *ptr_pair = reinterpret_cast<const unsigned *>(wave_smem + fused.ptr) + (lane >> 1) * G * K;
+            const long long ptr_words = ((long long)(args.blocks8 - 1) * kWave + G) * K;
+            uint8_t *row_read = lds_rows + lane * 2 * AL;
+            trace_walk<true>(t, ptr_pair, ptr_words, lane & 1, wave_ends[lane], lds_reads + lane * Rs, lds_refs + lane * Fs,
+                             row_read, row_read + AL, my_idx);
+            short *out = args.out_idx + (w.pair0 + lane) * 4;
+            out[0] = my_idx[0];
+            out[1] = my_idx[1];
+            out[2] = my_idx[2];
+            out[3] = my_idx[3];
+        }
+        __syncthreads();
+        // rows of the wave's pairs are one contiguous run of the output: dwords where the address allows, else bytes
+        uint8_t *dst = args.out_rows + w.pair0 * 2 * AL;
+        const int bytes = pairs_here * 2 * AL;
+        if ((reinterpret_cast<unsigned long long>(dst) & 3ull) == 0) {
+            for (int x = lane; x < bytes / 4; x += kWave) reinterpret_cast<unsigned *>(dst)[x] = reinterpret_cast<const unsigned *>(lds_rows)[x];
+            for (int x = (bytes & ~3) + lane; x < bytes; x += kWave) dst[x] = lds_rows[x];
+        } else {
+            for (int x = lane; x < bytes; x += kWave) dst[x] = lds_rows[x];
+        }
+    }
 }
 
 // Affine-gap (Gotoh) fill -- an extension, the reference has no affine model.  Per cell two
@@ -1115,199 +1414,5 @@ align_fill_sse_kernel(const FillArgs args) {
     write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l);
 }
 
-struct TraceArgs {
-    const uint8_t *reads;
-    const uint8_t *refs;
-    const unsigned *ptr;
-    const EndCell *ends;
-    uint8_t *rows;            // n * 2 * (R+F), pre-zeroed
-    short *idx;               // n * 4: readStart, readEnd, refStart, refEnd
-    long long n;
-    int R, F;
-    int G, K, pad_rows, blocks8;
-    int alg;
-    int affine;               // 1: pointer blocks hold K H-code words followed by K gap-code words
-    int sse_policy;           // 1: stored states are 0 START, 1 UP, 2 LEFT, 3 DIAG (SSE/AVX kernel rules)
-    int tagged;               // 1: codes are the tags of align_fill_tag_kernel (2 DIAG, 1 UP, 0 LEFT);
-                              // 2: 4-bit codes of align_fill_affine_tag_kernel, K words per 4-step block
-    short match, mismatch, gap_read, gap_ref;
-    short open_read, ext_read, open_ref, ext_ref;
-    int strip_rows;           // > 0: the read was swept in row strips of this many padded rows (strip_kernels.hip.h),
-    long long strip_words;    //      each with its own region of the pointer stream, this many dwords apart
-};
-
-typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
-
-#ifndef VALIGN_KERNEL_PART_TU      // not a template: defined once, in the plugin's main translation unit
-// One lane per pair.  The walk is a chain of dependent loads, so the kernel is bound by the
-// number of memory transactions: pointer words are fetched 16 bytes (4 rows x 8 columns) at a
-// time, read/ref bases 4 at a time, and the two output rows are written as dwords.
-__global__ void __launch_bounds__(256)
-traceback_kernel(const TraceArgs a) {
-    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n) return;
-    const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
-    const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;      // words per lane and block of steps
-    const uint8_t *read = a.reads + pair * R;
-    const uint8_t *ref = a.refs + pair * F;
-    uint8_t *row_read = a.rows + pair * 2 * AL;
-    uint8_t *row_ref = row_read + AL;
-    const EndCell e = a.ends[pair];
-    // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
-    const int ppw = 2 * (kWave / G);
-    const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
-    long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
-    if (a.strip_rows > 0) ptr_words += (long long)((R + a.pad_rows) / a.strip_rows - 1) * a.strip_words;   // ... of the last strip
-    const int half_shift = (int)(pair & 1) * 16;
-
-    int i = e.read_pos, j = e.ref_pos, h = e.score;
-    int k = AL - 2;
-    long long cached_at = -1;              // first word index held in c0..c3 (multiple of 4)
-    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int rd_at = -1, rf_at = -1;            // index / 4 of the cached read / ref dwords
-    unsigned rd_w = 0, rf_w = 0;
-    unsigned out_r = 0, out_f = 0;         // up to 4 pending output bytes per row, newest in the low byte
-    int pending = 0;
-    int state = 0;                         // affine only: 0 at H, 1 inside F (gap in the ref), 2 inside E
-
-    auto base_at = [](const uint8_t *seq, int len, int pos, int &at, unsigned &w) -> unsigned {
-        if ((pos >> 2) != at) {
-            at = pos >> 2;
-            const int b = at * 4;
-            if (b + 4 <= len) {
-                w = *reinterpret_cast<const u32_any_align *>(seq + b);
-            } else {
-                w = 0;
-                for (int x = 0; b + x < len; ++x) w |= (unsigned)seq[b + x] << (8 * x);
-            }
-        }
-        return (w >> (8 * (pos & 3))) & 0xFFu;
-    };
-    // 2-bit code of cell (i, j) from word `wi` of this pair-of-pairs, through a 4-word cache
-    auto code_at = [&](long long wi, int t) -> int {
-        const long long wb = wi & ~3ll;
-        if (wb != cached_at) {
-            cached_at = wb;
-            if (wb + 4 <= ptr_words) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
-                c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
-            } else {
-                c0 = ptr_pair[wb];
-                c1 = wb + 1 < ptr_words ? ptr_pair[wb + 1] : 0u;
-                c2 = wb + 2 < ptr_words ? ptr_pair[wb + 2] : 0u;
-                c3 = 0u;
-            }
-        }
-        const int sel = (int)(wi & 3);
-        const unsigned word = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
-        if (a.tagged == 2) return (int)((word >> (half_shift + 4 * (3 - (t & 3)))) & 15u);
-        return (int)((word >> (half_shift + 2 * (7 - (t & 7)))) & 3u);
-    };
-
-    while (k >= 0) {
-        if (state == 0) {
-            if (a.sse_policy) {
-                if (i < 0 || (a.alg == kAlgSW && j < 0)) break;      // row 0 (and SW column 0): START
-            } else if (a.alg == kAlgSW) {
-                if (h <= 0 || i < 0 || j < 0) break;    // cell == 0: START
-            } else {
-                if (i < 0) break;                       // row 0: START
-            }
-        }
-        int move;                                       // 0 DIAG, 1 UP (emit read, '-'), 2 LEFT
-        if (j < 0) {
-            move = 1;                                   // column 0 of the NW variant: UP all the way
-            state = 0;
-        } else {
-            int p = i + a.pad_rows;
-            long long region = 0;
-            if (a.strip_rows > 0) {                     // row strips: each has its own pointer region
-                const int strip = p / a.strip_rows;
-                p -= strip * a.strip_rows;
-                region = strip * a.strip_words;
-            }
-            const int l = p / K, q = p - l * K;
-            const int t = j + l;
-            const long long wi = region + ((long long)(a.tagged == 2 ? (t >> 2) : (t >> 3)) * kWave + l) * wpb + q;
-            if (a.tagged == 2) {
-                const int f4 = code_at(wi, t);          // [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
-                if (state == 0) {
-                    const int src = f4 >> 2;
-                    move = src == 2 ? 0 : (src == 1 ? 1 : 2);
-                    if (move != 0) {
-                        state = move;                   // nothing is emitted on entering a gap state
-                        continue;
-                    }
-                } else {
-                    move = state;
-                    if (state == 1) {
-                        if (f4 & 1) { h -= a.open_ref; state = 0; } else h -= a.ext_ref;
-                    } else {
-                        if (f4 & 2) { h -= a.open_read; state = 0; } else h -= a.ext_read;
-                    }
-                }
-            } else if (a.sse_policy) {
-                const int st = code_at(wi, t);          // 0 START, 1 UP, 2 LEFT, 3 DIAG
-                if (st == 0) break;
-                move = st == 3 ? 0 : st;
-            } else if (!a.affine) {
-                move = code_at(wi, t);
-                if (a.tagged) move = 2 - move;
-            } else if (state == 0) {
-                move = code_at(wi, t);                  // 0 DIAG, 1 enter F, 2 enter E
-                if (move != 0) {
-                    state = move;                       // nothing is emitted on entering a gap state
-                    continue;
-                }
-            } else {
-                const int bits = code_at(wi + K, t);    // bit0: F extended, bit1: E extended
-                move = state;
-                if (state == 1) {
-                    if (bits & 1) h -= a.ext_ref; else { h -= a.open_ref; state = 0; }
-                } else {
-                    if (bits & 2) h -= a.ext_read; else { h -= a.open_read; state = 0; }
-                }
-            }
-        }
-        unsigned br, bf;
-        if (move == 0) {
-            br = base_at(read, R, i, rd_at, rd_w);
-            bf = base_at(ref, F, j, rf_at, rf_w);
-            const int ca = base_class(br), cb = base_class(bf);
-            if (ca >= 1 && ca <= 4 && cb >= 1 && cb <= 4) h -= (ca == cb ? a.match : a.mismatch);
-            --i;
-            --j;
-        } else if (move == 1) {
-            br = base_at(read, R, i, rd_at, rd_w);
-            bf = '-';
-            if (!a.affine) h -= a.gap_ref;
-            --i;
-        } else {
-            br = '-';
-            bf = base_at(ref, F, j, rf_at, rf_w);
-            if (!a.affine) h -= a.gap_read;
-            --j;
-        }
-        out_r = (out_r << 8) | br;
-        out_f = (out_f << 8) | bf;
-        if (++pending == 4) {                           // bytes k .. k+3 of both rows, lowest address = newest
-            *reinterpret_cast<u32_any_align *>(row_read + k) = out_r;
-            *reinterpret_cast<u32_any_align *>(row_ref + k) = out_f;
-            pending = 0;
-        }
-        --k;
-    }
-    for (int x = 0; x < pending; ++x) {                 // k + 1 is the newest byte written
-        row_read[k + 1 + x] = (uint8_t)(out_r >> (8 * x));
-        row_ref[k + 1 + x] = (uint8_t)(out_f >> (8 * x));
-    }
-
-    short *out = a.idx + pair * 4;
-    out[0] = (short)(k + 1);
-    out[1] = (short)(AL - 1);
-    out[2] = (short)(k + 1);
-    out[3] = (short)(AL - 1);
-}
-#endif
 
 }  // namespace valign
