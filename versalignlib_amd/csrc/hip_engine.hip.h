@@ -453,7 +453,7 @@ public:
         }
         const void *fn = sc_.affine ? kLongAffineKernels[alg][wide ? 1 : 0]
                                     : kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
-        const int long_lds = LongLds<kLongG, kLongK>::kTotal;
+        const int long_lds = sc_.affine ? LongLds<kLongG, kLongK, true>::kTotal : LongLds<kLongG, kLongK, false>::kTotal;
         for (long long begin = 0; begin < n; begin += chunk) {
             const long long cnt = std::min(chunk, n - begin);
             a.reads = d_reads + (size_t)begin * R_;

@@ -76,7 +76,7 @@ struct Cell<true> {
     static __device__ __forceinline__ T from_bits(unsigned v) { return (int)v; }
 };
 
-template <int G, int K>
+template <int G, int K, bool AFFINE = false>
 struct LongLds {
     using geo = Geo<G, K>;
     static constexpr int kCodes = geo::kProfBytes;                        // [groups][kRing][2] bytes
@@ -84,7 +84,7 @@ struct LongLds {
     static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
     static constexpr int kInF = kOut + geo::kGroups * kRing * 4;          // affine: the F values of the boundary rows, same rings
     static constexpr int kOutF = kInF + geo::kGroups * kRing * 4;
-    static constexpr int kTotal = kOutF + geo::kGroups * kRing * 4;
+    static constexpr int kTotal = AFFINE ? kOutF + geo::kGroups * kRing * 4 : kInF;      // (LDS bounds the waves per CU: 9 at 16.7 KB)
 };
 
 // Columns [c_lo, c_hi] swept by strip s.  c_lo is a multiple of 4 (16-byte ring accesses).
@@ -112,7 +112,7 @@ template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 score_long_kernel(const LongArgs args) {
     using geo = Geo<G, K>;
-    using lay = LongLds<G, K>;
+    using lay = LongLds<G, K, AFFINE>;
     using ops = Cell<WIDE>;
     using cell_t = typename ops::T;
     static_assert(kPhase >= G - 1, "a phase must cover the pipeline skew");
