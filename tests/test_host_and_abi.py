@@ -133,3 +133,23 @@ def test_cigar_of_known_answer_alignments():
         r = np.ascontiguousarray(rows[0])
         if host.lib().vh_cigar(r.ctypes.data, r.ctypes.data + r.shape[1], int(idx[0, 0]), int(idx[0, 1]), 0, buf, 2) < 0:
             raise host.PluginError("too small")
+
+
+def test_reference_timing_protocol_and_alloc_probe():
+    """vh_time_calls is the reference host's timing loop (time_kernel, src/impl/main.cpp:268-292) -- exercised here
+    against the reference's own Default kernel (CPU); vh_alloc_probe measures what 2n operator new[] rows cost."""
+    default = ref_kernel("Default")
+    if not default:
+        pytest.skip("oracle/_ref not built")
+    R, F, n = 24, 40, 64
+    reads, refs = synth.make_pairs(n, R, F, seed=3)
+    with host.Plugin(default, R, F, num_threads=2) as k:
+        for align in (True, False):
+            for free_between in (False, True):
+                total, per_call = k.time_calls(host.SW, reads, refs, reps=4, align=align, free_between=free_between)
+                assert len(per_call) == 4 and all(t > 0 for t in per_call)
+                assert abs(total - sum(per_call)) < 1e-9
+    alloc_s, free_s = host.alloc_probe(1000, R + F, 2)
+    assert alloc_s > 0 and free_s >= 0
+    with pytest.raises(host.PluginError):
+        host.alloc_probe(10, 0, 1)
