@@ -81,4 +81,7 @@ def test_random_configuration(case):
         assert bad.size == 0, (c, "idx", opt, bad[:5], idx[bad[:2]], eidx[bad[:2]])
         bad = np.nonzero((rows != erows).any(axis=(1, 2)))[0]
         assert bad.size == 0, (c, "rows", opt, bad[:5])
+        # the host-pointer entry: small calls take the direct path and, where a fused kernel exists, one launch
+        hrows, hidx = eng.align_host(opt, reads, refs, threads=2)
+        assert np.array_equal(hidx, eidx) and np.array_equal(hrows, erows), (c, "align_host", opt, eng.describe(opt, n)["direct_call"])
     eng.close()

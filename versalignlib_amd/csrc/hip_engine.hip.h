@@ -114,9 +114,11 @@ constexpr int kDefaultBlockLds = 64 * 1024;    // above this the kernel attribut
 
 // Long-read path (row strips + column phases, long_kernels.hip.h): one geometry.
 constexpr int kLongG = 16, kLongK = 10;
-static const void *const kLongAffineKernels[2][2] = {       // [alg][int32 cells]
-    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true, true>},
-    {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true, true>}};
+static const void *const kLongAffineKernels[2][2][2] = {       // [alg][same scores both ways][int32 cells]
+    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true, true>},
+     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true, true>}},
+    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true, true>},
+     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, true, true>}}};
 static const void *const kLongKernels[2][2][2] = {     // [alg][gap_read == gap_ref][int32 cells]
     {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true>},
      {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true>}},
@@ -451,7 +453,8 @@ public:
             brow_bytes_ = (size_t)waves * bytes_per_wave;
             hip_check(hipMalloc((void **)&d_brow_, brow_bytes_), "hipMalloc(boundary rows)");
         }
-        const void *fn = sc_.affine ? kLongAffineKernels[alg][wide ? 1 : 0]
+        const bool affine_sym = sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
+        const void *fn = sc_.affine ? kLongAffineKernels[alg][affine_sym ? 1 : 0][wide ? 1 : 0]
                                     : kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
         const int long_lds = sc_.affine ? LongLds<kLongG, kLongK, true>::kTotal : LongLds<kLongG, kLongK, false>::kTotal;
         for (long long begin = 0; begin < n; begin += chunk) {

@@ -107,7 +107,8 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
 }
 
 // AFFINE: Gotoh recurrence (E along the row in registers like H; F down the column -- through the lanes by DPP
-// and from strip to strip through a second boundary row next to H's).  SYM is ignored then.
+// and from strip to strip through a second boundary row next to H's).  SYM then means open_read == open_ref and
+// ext_read == ext_ref: H - open is computed once per cell.
 template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 score_long_kernel(const LongArgs args) {
@@ -198,6 +199,12 @@ score_long_kernel(const LongArgs args) {
         cell_t El[AFFINE ? K : 1];
 #pragma unroll
         for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = border_f;
+        // AFFINE && SYM (same open / extend both ways): H - open of the previous column, computed once per cell and
+        // shared by E of this column and F of the next row (score_kernel's kGapAffineSym)
+        cell_t HOl[(AFFINE && SYM) ? K : 1];
+#pragma unroll
+        for (int q = 0; q < ((AFFINE && SYM) ? K : 1); ++q)
+            HOl[q] = (ALG == kAlgSW) ? ops::sub0(ops::bc(0), o_ref) : ops::adds(ops::bc(0), o_ref);
         cell_t f_last = border_f;
         cell_t up0 = ops::bc(0), h_last = ops::bc(0);
         if (l == 0 && c_lo - 1 >= p_lo && c_lo - 1 <= p_hi)     // diagonal neighbour of the first swept column
@@ -253,22 +260,34 @@ score_long_kernel(const LongArgs args) {
                     // ahead, between the links of the dependent chain F -> H down the column (see score_kernel)
                     auto pass1 = [&](int q) __attribute__((always_inline)) -> cell_t {
                         const cell_t d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
-                        const cell_t e = (ALG == kAlgSW) ? ops::mx(ops::sub0(El[q], e_read), ops::sub0(Hl[q], o_read))
-                                                         : ops::mx(ops::adds(El[q], e_read), ops::adds(Hl[q], o_read));
+                        cell_t e;
+                        if constexpr (SYM)
+                            e = ops::mx((ALG == kAlgSW) ? ops::sub0(El[q], e_read) : ops::adds(El[q], e_read), HOl[q]);
+                        else
+                            e = (ALG == kAlgSW) ? ops::mx(ops::sub0(El[q], e_read), ops::sub0(Hl[q], o_read))
+                                                : ops::mx(ops::adds(El[q], e_read), ops::adds(Hl[q], o_read));
                         El[q] = e;
                         if (ALG == kAlgSW) best = ops::mx(best, d);
                         return ops::mx(d, e);
                     };
                     cell_t f = fup0;
+                    cell_t ho = (ALG == kAlgSW) ? ops::sub0(up0, o_ref) : ops::adds(up0, o_ref);      // SYM: H - open of the row above
                     cell_t m_cur = pass1(0);
 #pragma unroll
                     for (int q = 0; q < K; ++q) {
-                        f = (ALG == kAlgSW) ? ops::mx(ops::sub0(f, e_ref), ops::sub0(h, o_ref))
-                                            : ops::mx(ops::adds(f, e_ref), ops::adds(h, o_ref));
+                        if constexpr (SYM)
+                            f = ops::mx((ALG == kAlgSW) ? ops::sub0(f, e_ref) : ops::adds(f, e_ref), ho);
+                        else
+                            f = (ALG == kAlgSW) ? ops::mx(ops::sub0(f, e_ref), ops::sub0(h, o_ref))
+                                                : ops::mx(ops::adds(f, e_ref), ops::adds(h, o_ref));
                         cell_t m_next = ops::bc(0);
-                        if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] is overwritten
+                        if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] (and HOl[q]) are overwritten
                         h = ops::mx(m_cur, f);
                         Hl[q] = h;
+                        if constexpr (SYM) {
+                            ho = (ALG == kAlgSW) ? ops::sub0(h, o_ref) : ops::adds(h, o_ref);
+                            HOl[q] = ho;
+                        }
                         m_cur = m_next;
                     }
                     f_last = f;

@@ -175,9 +175,10 @@ class Engine:
             raise HipKernelError(_err())
         return scores
 
-    def align_host(self, opt, reads, refs, threads=1):
+    def align_host(self, opt, reads, refs, threads=1, out=None):
         """Host-pointer path of compute_alignments into contiguous numpy buffers (no operator new[] blocks):
-        -> rows uint8 [n, 2, R+F], idx int16 [n, 4]."""
+        -> rows uint8 [n, 2, R+F], idx int16 [n, 4].  `out` = (rows, idx) of an earlier call is written in place
+        (a caller that loops keeps its result buffers, like any FFI binding would)."""
         import numpy as np
         n = reads.shape[0]
         assert reads.dtype == np.uint8 and refs.dtype == np.uint8 and reads.flags.c_contiguous and refs.flags.c_contiguous
@@ -185,8 +186,13 @@ class Engine:
         rp = (reads.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.read_length)).astype(np.uint64)
         fp = (refs.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(self.ref_length)).astype(np.uint64)
         AL = self.read_length + self.ref_length
-        rows = np.zeros((n, 2, AL), dtype=np.uint8)
-        idx = np.zeros((n, 4), dtype=np.int16)
+        if out is not None:
+            rows, idx = out
+            assert rows.shape == (n, 2, AL) and rows.dtype == np.uint8 and rows.flags.c_contiguous
+            assert idx.shape == (n, 4) and idx.dtype == np.int16 and idx.flags.c_contiguous
+        else:
+            rows = np.zeros((n, 2, AL), dtype=np.uint8)
+            idx = np.zeros((n, 4), dtype=np.int16)
         rc = lib().valign_hip_align_host(self._h, int(opt), n, rp.ctypes.data, fp.ctypes.data, rows.ctypes.data,
                                          idx.ctypes.data, int(threads))
         if rc != 0:
