@@ -330,13 +330,29 @@ def test_alignments_config5_shape():
             hip.compute_alignments(host.NW, reads, refs)
 
 
+@pytest.mark.parametrize("R,F,n,seed", [(3000, 3500, 7, 11), (2500, 700, 9, 12), (2049, 300, 5, 13), (4100, 6000, 3, 14)])
+@pytest.mark.parametrize("aff", [(-5, -1, -5, -1), (-6, -2, -4, -1), (-3, -3, -3, -3)])
+def test_affine_alignments_of_long_reads(R, F, n, seed, aff):
+    """Affine alignments by row strips (E in registers, F handed from strip to strip, two code streams) against the
+    Gotoh oracle the enumeration fixtures pin; open == extend also against the linear oracle."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.15, short_frac=0.25,
+                                   lowercase_frac=0.05, junk_frac=0.03)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+    keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, **keys) as hip:
+        for opt in (host.SW, host.NW):
+            if opt == host.NW and (min(R, F) + 2) * min(aff) < -15000:
+                continue                      # cells of the NW variant would leave the affine int16 range: refused
+            got = hip.compute_alignments(opt, reads, refs, normalise=False)
+            _same_alignments(got, cpu_ref.align(opt, reads, refs, sc, threads=8, affine=True), (R, F, aff, opt))
+            if aff[0] == aff[1] and aff[2] == aff[3]:
+                _same_alignments(got, cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, aff[0], aff[2]), threads=8),
+                                 ("degenerate", opt))
+
+
 def test_long_alignments_refuse_what_they_do_not_implement():
     R, F = 3000, 500
     reads, refs = synth.make_pairs(2, R, F, seed=5)
-    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5,
-                     score_gap_extend_ref=-1) as hip:
-        with pytest.raises(host.PluginError, match="linear gap model"):
-            hip.compute_alignments(host.SW, reads, refs)
     with host.Plugin(build.HIP_PLUGIN, R, F, traceback_policy=1) as hip:
         with pytest.raises(host.PluginError, match="default tie-breaks"):
             hip.compute_alignments(host.SW, reads, refs)

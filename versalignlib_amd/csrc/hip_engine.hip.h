@@ -130,13 +130,17 @@ struct StripGeometry {
     int K;
     WaveLds (*lds)(int R, int F);
     const void *kernel[2];
+    const void *affine_kernel[2];      // nullptr: too many rows per lane for the affine kernel's registers
 };
 static const StripGeometry kStripGeometries[] = {
-    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}},
-    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}},
-    {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>}},
-    {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>}},
-    {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>}},
+    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}},
+    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}},
+    {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
+     {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}},
+    {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
+     {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}},
+    {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
+     {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}},
 };
 
 // Small batches: fill + traceback in one launch, pointer stream in LDS (align_fill_tag_kernel<..., FUSED>)
@@ -834,17 +838,18 @@ public:
 
     // Reads beyond one register sweep: row strips of 64 * K rows, one launch per strip in stream order, boundary
     // rows ping-pong through HBM, one pointer region per strip, then the same traceback kernel (strip_kernels.hip.h).
-    // Linear gaps, Default tie-breaks, int16 cells (the reference's; where they would wrap the call is refused by
-    // check_int16_range above instead of wrapping silently).
+    // Linear or affine gaps, Default tie-breaks, int16 cells (the reference's; where they would wrap the call is refused
+    // by check_int16_range above instead of wrapping silently).
     void align_strips_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
                              short *d_idx, hipStream_t stream) {
-        if (sc_.affine || sse_policy_)
-            throw std::runtime_error("compute_alignments for read_length > 2048 (row strips) implements the linear gap model "
-                                     "with the default tie-breaks only");
+        if (sse_policy_)
+            throw std::runtime_error("compute_alignments for read_length > 2048 (row strips) implements the default tie-breaks only");
+        const bool affine = sc_.affine;
         const StripGeometry *geo = nullptr;
         WaveLds lds{};
         for (int budget : {kMaxBlockLds / 2, kMaxBlockLds}) {            // two waves per CU if possible
             for (const StripGeometry &g : kStripGeometries) {
+                if (affine && !g.affine_kernel[alg]) continue;
                 const WaveLds w = g.lds(64 * g.K, F_);
                 if (w.total <= budget && !geo) {
                     geo = &g;
@@ -858,8 +863,9 @@ public:
         const int strips = std::max(1, (R_ + rows - 1) / rows), pad_total = strips * rows - R_;
         const int blocks8 = (F_ + 63 + 7) / 8;
         const int row_dwords = ((F_ + 71) / 64 + 2) * 64;
-        const size_t strip_words = (size_t)blocks8 * 64 * K;                       // per wave (= pair-of-pairs) and strip
-        const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_dwords * 4;
+        const size_t strip_words = (size_t)blocks8 * 64 * K * (affine ? 2 : 1);    // per wave (= pair-of-pairs) and strip
+        const int row_sets = affine ? 2 : 1;                                       // boundary rows: H, and F beside it (affine)
+        const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_sets * row_dwords * 4;
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
         const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
@@ -895,7 +901,7 @@ public:
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
         hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_);
         hip_check(hipGetLastError(), "hipLaunchKernel(first_invalid_kernel)");
-        const void *fn = geo->kernel[alg];
+        const void *fn = affine ? geo->affine_kernel[alg] : geo->kernel[alg];
         if (lds.total > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds.total),
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -908,8 +914,10 @@ public:
                 a.ptr = d_ptr_ + (size_t)s * cnt_waves * strip_words;
                 a.ends = d_ends_;
                 a.first_bad = d_first_bad_ + 2 * begin;
-                a.top = boundary + (size_t)((s & 1) ^ 1) * waves * row_dwords;
-                a.bottom = boundary + (size_t)(s & 1) * waves * row_dwords;
+                a.top = boundary + (size_t)((s & 1) ^ 1) * row_sets * waves * row_dwords;
+                a.bottom = boundary + (size_t)(s & 1) * row_sets * waves * row_dwords;
+                a.top_f = a.top + (size_t)waves * row_dwords;                // (only read / written by the affine kernel)
+                a.bottom_f = a.bottom + (size_t)waves * row_dwords;
                 a.n = cnt;
                 a.R = R_;
                 a.F = F_;
@@ -924,6 +932,10 @@ public:
                 a.mismatch = (short)sc_.mismatch;
                 a.gap_read = (short)sc_.gap_read;
                 a.gap_ref = (short)sc_.gap_ref;
+                a.open_read = (short)sc_.open_read;
+                a.ext_read = (short)sc_.ext_read;
+                a.open_ref = (short)sc_.open_ref;
+                a.ext_ref = (short)sc_.ext_ref;
                 void *kargs[] = {&a};
                 hip_check(hipLaunchKernel(fn, dim3((unsigned)cnt_waves), dim3(kWave), kargs, (size_t)lds.total, stream),
                           "hipLaunchKernel(align_strip_kernel)");
@@ -947,6 +959,11 @@ public:
             t.mismatch = (short)sc_.mismatch;
             t.gap_read = (short)sc_.gap_read;
             t.gap_ref = (short)sc_.gap_ref;
+            t.affine = affine ? 1 : 0;
+            t.open_read = (short)sc_.open_read;
+            t.ext_read = (short)sc_.ext_read;
+            t.open_ref = (short)sc_.open_ref;
+            t.ext_ref = (short)sc_.ext_ref;
             t.strip_rows = rows;
             t.strip_words = (long long)(cnt_waves * strip_words);
             void *targs[] = {&t};

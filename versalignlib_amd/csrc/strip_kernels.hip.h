@@ -14,8 +14,10 @@
 //   * what needs the whole pair -- the first invalid read / ref position of the NW variant's end-cell rule
 //     (DefaultKernel.cpp:307-315, 348-350) -- is computed up front by first_invalid_kernel; the Smith-Waterman end
 //     cell (row-major first maximum, :252-256) is the best of the strips' own, earlier strips winning ties.
-// Linear gap model and the Default kernel's tie-breaks (pointer by equality tests, as align_fill_kernel): the
-// tagged-cell kernels keep 4 x cell in int16, which long reads outgrow.
+// Default tie-breaks, pointers by equality tests (the tagged-cell kernels keep 4 x / 8 x cell in int16, which long reads
+// outgrow): the linear model as align_fill_kernel, the affine one (AFFINE) as align_fill_affine_kernel -- E in
+// registers along the row, F down the column and from strip to strip through a second boundary row, two 2-bit
+// code streams (source of H; E / F extended) per cell.
 #pragma once
 
 #include "trace_kernels.hip.h"
@@ -30,6 +32,8 @@ struct StripArgs {
     const int *first_bad;       // n x 2: first invalid read / ref position (else R / F), first_invalid_kernel
     const unsigned *top;        // boundary row above this strip: [pair-of-pairs][row_dwords] (unused for strip 0)
     unsigned *bottom;           // boundary row below
+    const unsigned *top_f;      // affine: F of the same rows
+    unsigned *bottom_f;
     long long n;
     int R, F;
     int prof_area, refc_stride, wave_lds;
@@ -38,6 +42,7 @@ struct StripArgs {
     int row_dwords;             // dwords per boundary row: a multiple of 64, >= F + 135 (whole 64-column stores / loads)
     short match, mismatch;
     short gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;     // affine
 };
 
 #ifndef VALIGN_KERNEL_PART_TU
@@ -71,9 +76,10 @@ first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int
 }
 #endif
 
-template <int K, int ALG>
+template <int K, int ALG, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 align_strip_kernel(const StripArgs args) {
+    constexpr int W = AFFINE ? 2 * K : K;                             // pointer words per lane and block
     constexpr int G = 64;
     using geo = Geo<G, K>;
     const int lane = threadIdx.x;
@@ -93,8 +99,15 @@ align_strip_kernel(const StripArgs args) {
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
-    s16x2 one = pk(1), four = pk(4), fifteen = pk(15);
-    asm volatile("" : "+v"(one), "+v"(four), "+v"(fifteen));     // keep the packed forms (see align_fill_kernel)
+    s16x2 one = pk(1), two = pk(2), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(two), "+v"(four), "+v"(fifteen));     // keep the packed forms (see align_fill_kernel)
+    // affine: magnitudes for the SW floor-at-zero subtract, signed saturating addends for the NW variant
+    const s16x2 o_read = pk(ALG == kAlgSW ? (short)-args.open_read : args.open_read), e_read = pk(ALG == kAlgSW ? (short)-args.ext_read : args.ext_read);
+    const s16x2 o_ref = pk(ALG == kAlgSW ? (short)-args.open_ref : args.open_ref), e_ref = pk(ALG == kAlgSW ? (short)-args.ext_ref : args.ext_ref);
+    const s16x2 border_f = pk((AFFINE && ALG == kAlgNW) ? kNegInf : (short)0);
+    auto gap_add = [](s16x2 v, s16x2 c) __attribute__((always_inline)) {
+        return (ALG == kAlgSW) ? pk_sub_floor0(v, c) : pk_add_sat(v, c);
+    };
 
     int ir[2], jr[2];
 #pragma unroll
@@ -105,16 +118,22 @@ align_strip_kernel(const StripArgs args) {
     }
 
     s16x2 Hl[K], code[K], acc[K];
+    s16x2 El[AFFINE ? K : 1], code_g[AFFINE ? K : 1], acc_g[AFFINE ? K : 1];
     s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
     short nw_seed[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         const int pos = row0 + l * K + q;              // read position of the row (negative: padding)
         short border = 0;
-        if (ALG == kAlgNW) border = pos < 0 ? (short)0 : (short)((pos + 1) * args.gap_ref);   // column 0 of the NW variant
+        if (ALG == kAlgNW)                             // column 0 of the NW variant: a gap of pos + 1 read bases
+            border = pos < 0 ? (short)0 : (AFFINE ? (short)(args.open_ref + pos * args.ext_ref) : (short)((pos + 1) * args.gap_ref));
         Hl[q] = pk(border);
         code[q] = pk(0);
         acc[q] = pk(0);
+        if (AFFINE) {
+            El[q] = border_f;
+            code_g[q] = acc_g[q] = pk(0);
+        }
         if (ALG == kAlgSW) {
             rb[q] = pk(0);
             fc[q] = pk(0);
@@ -129,26 +148,33 @@ align_strip_kernel(const StripArgs args) {
         rb[0] = s16x2{nw_seed[0], nw_seed[1]};
         fc[0] = pk((short)l);
     }
-    s16x2 h_last = Hl[K - 1];
+    s16x2 h_last = Hl[K - 1], f_last = border_f;
     // the row above the strip at column -1 (diagonal neighbour of lane 0's first cell): column 0's border
     s16x2 up0 = pk(0);
-    if (ALG == kAlgNW && l == 0 && row0 - 1 >= 0) up0 = pk((short)(row0 * args.gap_ref));
+    if (ALG == kAlgNW && l == 0 && row0 - 1 >= 0)
+        up0 = pk(AFFINE ? (short)(args.open_ref + (row0 - 1) * args.ext_ref) : (short)(row0 * args.gap_ref));
     int j = -l;
 
-    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
+    unsigned *ptr_lane = pointer_stream_lane<G, K, W>(args.ptr, w.pair0, args.blocks8, lane);
     const long long pp = w.pair0 / 2;
-    const unsigned *top = args.top + pp * args.row_dwords;
-    unsigned *bottom = args.bottom + pp * args.row_dwords;
+    const unsigned *top = args.top + pp * args.row_dwords, *top_f = args.top_f + pp * args.row_dwords;
+    unsigned *bottom = args.bottom + pp * args.row_dwords, *bottom_f = args.bottom_f + pp * args.row_dwords;
     const bool has_top = args.strip > 0, has_bottom = args.strip + 1 < args.strips;
     // 64 columns of the row above per lane-register, fetched 64 steps ahead (row_dwords covers the reads)
+    const unsigned border_f_bits = as_u32(border_f);
     unsigned top_cur = 0u, top_next = has_top ? top[lane] : 0u;
-    unsigned bot_acc = 0u;
+    unsigned topf_cur = border_f_bits, topf_next = (AFFINE && has_top) ? top_f[lane] : border_f_bits;
+    unsigned bot_acc = 0u, botf_acc = 0u;
 
     const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;   // whole 8-step blocks
     for (int t = 0; t < steps; ++t) {
         if ((t & 63) == 0) {
             top_cur = top_next;
             top_next = (has_top && t + 64 + lane < args.row_dwords) ? top[t + 64 + lane] : 0u;
+            if (AFFINE) {
+                topf_cur = topf_next;
+                topf_next = (has_top && t + 64 + lane < args.row_dwords) ? top_f[t + 64 + lane] : border_f_bits;
+            }
         }
         const s16x2 diag0 = up0;
         const unsigned above = (unsigned)__builtin_amdgcn_readlane((int)top_cur, t & 63);      // H(row above, column t)
@@ -156,7 +182,58 @@ align_strip_kernel(const StripArgs args) {
         unsigned from_lane = from_prev_lane(as_u32(h_last));
         asm volatile("" : "+v"(from_lane));
         up0 = as_pk(l == 0 ? above : from_lane);
-        if ((unsigned)j < (unsigned)F) {
+        s16x2 fup0 = border_f;
+        if (AFFINE) {
+            const unsigned above_f = (unsigned)__builtin_amdgcn_readlane((int)topf_cur, t & 63);
+            unsigned f_lane = from_prev_lane(as_u32(f_last));
+            asm volatile("" : "+v"(f_lane));
+            fup0 = as_pk(l == 0 ? above_f : f_lane);
+        }
+        if (AFFINE && (unsigned)j < (unsigned)F) {
+            // Gotoh recurrence with the pointers by equality tests (align_fill_affine_kernel): H code 0 DIAG / 1 from F /
+            // 2 from E (priority DIAG > F > E), gap code bit 1 = E extended, bit 0 = F extended (open preferred on ties)
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            const s16x2 tt = pk((short)t);
+            s16x2 d[K], m[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                const s16x2 e_open = gap_add(Hl[q], o_read), e_extd = gap_add(El[q], e_read);
+                const s16x2 e = pk_max(e_extd, e_open);
+                El[q] = e;
+                code_g[q] = pk_min_u(e - e_open, one);
+                m[q] = pk_max(d[q], e);
+            }
+            s16x2 h = up0, f = fup0, hs = pk(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 f_open = gap_add(h, o_ref), f_extd = gap_add(f, e_ref);
+                f = pk_max(f_extd, f_open);
+                h = pk_max(m[q], f);
+                Hl[q] = h;
+                const s16x2 nd = pk_min_u(h - d[q], one), nf = pk_min_u(h - f, one);
+                code[q] = (s16x2)((u16x2)nd << (u16x2)nf);
+                code_g[q] = pk_mad_u(code_g[q], two, pk_min_u(f - f_open, one));
+                if (ALG == kAlgSW) {
+                    const s16x2 changed = (rb[q] - h) >> fifteen;
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = pk_max(rb[q], h);
+                } else {
+                    hs = pk_mad_u(h, sel[q], hs);
+                }
+            }
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = h;
+            f_last = f;
+        }
+        if (!AFFINE && (unsigned)j < (unsigned)F) {
             const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
             s16x2 S[K];
             fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
@@ -196,7 +273,22 @@ align_strip_kernel(const StripArgs args) {
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, code[q]);
-        if ((t & 7) == 7) finish_block<K>(ptr_lane, t >> 3, acc);
+        if (AFFINE) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc_g[q] = pk_mad_u(acc_g[q], four, code_g[q]);
+        }
+        if ((t & 7) == 7) {
+            if constexpr (AFFINE) {               // K words of H codes followed by K words of gap codes
+                unsigned w8[2 * K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) w8[q] = as_u32(acc[q]);
+#pragma unroll
+                for (int q = 0; q < K; ++q) w8[K + q] = as_u32(acc_g[q]);
+                store_block_words<2 * K>(pointer_stream_block<2 * K>(ptr_lane, t >> 3), w8);
+            } else {
+                finish_block<K>(ptr_lane, t >> 3, acc);
+            }
+        }
         // bottom row of the strip: lane 63 finished column t - 63
         if (has_bottom) {
             const int col = t - (G - 1);
@@ -204,6 +296,11 @@ align_strip_kernel(const StripArgs args) {
                 const int v = __builtin_amdgcn_readlane((int)as_u32(h_last), G - 1);
                 bot_acc = lane == (col & 63) ? (unsigned)v : bot_acc;
                 if ((col & 63) == 63 || t == steps - 1) bottom[(col & ~63) + lane] = bot_acc;
+                if (AFFINE) {
+                    const int vf = __builtin_amdgcn_readlane((int)as_u32(f_last), G - 1);
+                    botf_acc = lane == (col & 63) ? (unsigned)vf : botf_acc;
+                    if ((col & 63) == 63 || t == steps - 1) bottom_f[(col & ~63) + lane] = botf_acc;
+                }
             }
         }
         ++j;
