@@ -1343,6 +1343,8 @@ private:
         if (pairs <= staged_pairs_) return;
         release_staging();
         for (int s = 0; s < kSlots; ++s) {
+            // (write-combined pinned memory for the input staging was tried: no gain -- the call is bound by the H2D
+            // copies, 12-14 ms per 650 MB while the host threads gather, and by what else runs on the box)
             hip_check(hipHostMalloc((void **)&h_reads_[s], std::max<size_t>((size_t)pairs * R_, 16), hipHostMallocDefault), "hipHostMalloc");
             hip_check(hipHostMalloc((void **)&h_refs_[s], std::max<size_t>((size_t)pairs * F_, 16), hipHostMallocDefault), "hipHostMalloc");
             hip_check(hipHostMalloc((void **)&h_scores_[s], sizeof(short) * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
