@@ -37,6 +37,9 @@ echo "align pmc done"
   python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 2;
   python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 1 --opt 1; } 2>&1 | grep -v amdgpu.ids > $OUT/long_reads.txt || exit 1
 echo "sweeps done"
+bash tools/pmc_long.sh long_lin > $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_lin 65536 > $OUT/pmc_long.json
+bash tools/pmc_long.sh long_aff --affine 1 >> $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_aff 65536 > $OUT/pmc_long_affine.json
+echo "long pmc done"
 { echo "# tools/microbench/bin/host_alloc <pairs> <threads> <mode 0 plain / 1 arena primed / 2 allocate first>: 2n new char[650] + copy, caller frees";
   for m in 0 1 2; do ./tools/microbench/bin/host_alloc 1048576 16 $m 3; done; echo "# nproc / cpu.max"; nproc; cat /sys/fs/cgroup/cpu.max; } > $OUT/host_alloc.txt 2>&1
 echo "all done"

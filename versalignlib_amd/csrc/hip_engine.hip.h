@@ -693,11 +693,12 @@ public:
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
         const size_t bytes_per_pp = (size_t)G * blocks8 * K * 4 * ((sc_.affine && !affine_tagged) ? 2 : 1);
         // Pointer scratch: as much of the batch per launch as memory allows (a 1 M-pair launch keeps
-        // the latency-bound traceback kernel at full occupancy), capped at 24 GiB and half the free HBM.
+        // the traceback kernel at full occupancy), capped at 64 GiB -- one launch for a million affine pairs of
+        // 150 x 500 (43.6 GB) on a 288 GB device -- and half the free HBM.
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
         const size_t have = trace_bytes_;
-        const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
+        const size_t cap = std::min<size_t>(64ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
         long long chunk = (long long)(cap / bytes_per_pp) * 2;
         chunk = std::max(ppb, chunk / ppb * ppb);
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
