@@ -1028,18 +1028,14 @@ public:
                 host_stats_.direct = 2;
                 return;
             }
-            const bool one_copy = true;              // the slot's row buffers have room for the coordinates behind the rows
-            short *d_idx = one_copy ? (short *)(d_rows_[0] + rows_bytes) : d_idx_[0];
+            // rows and coordinates sit next to each other in the slot's row buffer (it has room for both) and come
+            // back in ONE copy
+            short *d_idx = (short *)(d_rows_[0] + rows_bytes);
             align_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), d_rows_[0], d_idx, kernels);
-            if (one_copy) {
-                hip_check(hipMemcpyAsync(h_rows_[0], d_rows_[0], all_bytes, hipMemcpyDeviceToHost, kernels), "D2H rows + idx");
-            } else {
-                hip_check(hipMemcpyAsync(h_rows_[0], d_rows_[0], (size_t)n * 2 * AL, hipMemcpyDeviceToHost, kernels), "D2H rows");
-                hip_check(hipMemcpyAsync(h_idx_[0], d_idx_[0], sizeof(short) * 4 * (size_t)n, hipMemcpyDeviceToHost, kernels), "D2H idx");
-            }
+            hip_check(hipMemcpyAsync(h_rows_[0], d_rows_[0], all_bytes, hipMemcpyDeviceToHost, kernels), "D2H rows + idx");
             hip_check(hipStreamSynchronize(kernels), "hipStreamSynchronize");
             auto t2 = std::chrono::steady_clock::now();
-            scatter(alignments, n, h_rows_[0], one_copy ? (const short *)(h_rows_[0] + rows_bytes) : h_idx_[0], threads);
+            scatter(alignments, n, h_rows_[0], (const short *)(h_rows_[0] + rows_bytes), threads);
             host_stats_.gather_ms = ms_between(t0, t1);
             host_stats_.wait_ms = ms_between(t1, t2);
             host_stats_.drain_ms = ms_between(t2, std::chrono::steady_clock::now());

@@ -88,7 +88,8 @@ typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword ac
 // (block 0), `ptr_words` the words from there to the end of the group's last block; `half` selects pair A / B of
 // the group.  Pointers may be global or LDS (generic): traceback_kernel walks the HBM scratch, the fused small-batch
 // kernel (align_fill_tag_kernel<..., FUSED>) the copy it keeps in LDS.
-template <bool BYTE_ROWS = false>      // BYTE_ROWS: rows in LDS -- one byte store per step, no dword at an odd address
+template <bool BYTE_ROWS = false>      // BYTE_ROWS: everything the walk touches sits in LDS (fused kernel) -- explicit LDS reads,
+                                       // one byte store per step (no dword at an odd LDS address)
 __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *ptr_pair, long long ptr_words, int half,
                                            const EndCell e, const uint8_t *read, const uint8_t *ref,
                                            uint8_t *row_read, uint8_t *row_ref, short *out) {
@@ -110,7 +111,9 @@ __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *p
         if ((pos >> 2) != at) {
             at = pos >> 2;
             const int b = at * 4;
-            if (b + 4 <= len) {
+            if (BYTE_ROWS) {            // LDS copy of the sequence, dword aligned and padded to a dword: a plain ds_read
+                w = *(lds_cu32 *)(lds_offset(seq) + b);
+            } else if (b + 4 <= len) {
                 w = *reinterpret_cast<const u32_any_align *>(seq + b);
             } else {
                 w = 0;
@@ -124,7 +127,10 @@ __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *p
         const long long wb = wi & ~3ll;
         if (wb != cached_at) {
             cached_at = wb;
-            if (wb + 4 <= ptr_words) {
+            if (BYTE_ROWS) {            // the stream sits in LDS, with other LDS of the block behind it: always the 16-byte read
+                const u32x4 v = *(lds_cu32x4 *)(lds_offset(ptr_pair) + 4 * (unsigned)wb);
+                c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+            } else if (wb + 4 <= ptr_words) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(ptr_pair + wb);
                 c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
             } else {
