@@ -403,3 +403,32 @@ def test_fused_small_batch_kernel(monkeypatch, R, F, n, seed, gaps):
         assert plain.describe(opt, n)["direct_call"] == 1
     eng.close()
     plain.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap_mb,overlap", [(0, True), (1024, True), (1024, False)])
+def test_tracebacks_beside_the_next_fill(monkeypatch, cap_mb, overlap):
+    """Large device batches run the walk of one part on a helper stream beside the fill of the next: one 7/8 + 1/8 cut
+    when the pointer scratch holds the batch, the two halves of the scratch in turn when it does not (forced here by
+    VALIGN_HIP_SCRATCH_CAP_MB).  Rows and coordinates must repeat with the period of the repeated block and equal the
+    oracle on it, with and without the helper stream."""
+    import torch
+    if cap_mb:
+        monkeypatch.setenv("VALIGN_HIP_SCRATCH_CAP_MB", str(cap_mb))
+    if not overlap:
+        monkeypatch.setenv("VALIGN_HIP_NO_OVERLAP", "1")
+    R, F, blk, reps = 150, 500, 2048, 70          # 143 360 pairs = 1.08e10 cells: above the overlap threshold
+    reads, refs = synth.make_pairs(blk, R, F, seed=77, indel_rate=0.01, junk_frac=0.02)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3))
+    d_reads = torch.from_numpy(reads).cuda().repeat(reps, 1).contiguous()
+    d_refs = torch.from_numpy(refs).cuda().repeat(reps, 1).contiguous()
+    for opt in (0, 1):
+        for _ in range(2):                      # the second call reuses scratch the first call's walks were reading
+            rows, idx = eng.align_device(opt, d_reads, d_refs)
+        torch.cuda.synchronize()
+        rows = rows.view(reps, blk, 2, R + F)
+        idx = idx.view(reps, blk, 4)
+        assert bool((rows == rows[0:1]).all()) and bool((idx == idx[0:1]).all())
+        erows, eidx = cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3), threads=8)
+        assert np.array_equal(idx[0].cpu().numpy(), eidx) and np.array_equal(rows[0].cpu().numpy(), erows)
+    eng.close()

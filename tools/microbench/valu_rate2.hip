@@ -18,7 +18,10 @@ enum Op {
     PK_MAX_I16, ADD_F32, FMA_F32, MAX_F32, MAX3_F32, MAX3_I32, PK_FMA_F32, PK_ADD_F32, ADD3_U32, MAX_I32,
     ADD_U32, PK_MAXIMUM3_F16, MAXIMUM3_F32, MAX3_I16, MED3_I32, MOV_DPP, AND_B32, MAD_U32_U24, PK_MAD_U16,
     PERM_B32, ADD_F32_CLAMP, PK_ADD_F16, MIN3_U32, SUB_SAT_U32, ADD_I32_SAT, MAX3_U16, CNDMASK, PK_MUL_F32, PK_MOV_B32,
-    DOT2_I32_I16, SAD_U16, LSHL_ADD, BFE, MAX_U16
+    DOT2_I32_I16, SAD_U16, LSHL_ADD, BFE, MAX_U16,
+    // second batch: the bit operations and 16-bit forms the tagged alignment kernels are made of, and a 1:1 mix
+    AND_OR_B32, BFI_B32, LSHL_OR_B32, OR3_B32, XOR_B32, OR_B32, LSHLREV_B32, PK_ADD_I16, PK_ADD_I16_CLAMP,
+    PK_SUB_U16_CLAMP, PK_LSHLREV_B16, SUB_U32, MAX_I16, ADD_U16, BITOP3_B32, MIX_PKMAX_AND, MIX_PKMAX_AND_2TO1
 };
 
 template <int OP>
@@ -71,6 +74,29 @@ __global__ void __launch_bounds__(512) rate(unsigned *out, unsigned seed, long l
             if (OP == SAD_U16) asm volatile("v_sad_u16 %0, %1, %2, %0" : "+v"(r[i]) : "v"(g), "v"(h));
             if (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(r[i]) : "v"(g));
             if (OP == BFE) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(r[i]));
+            if (OP == AND_OR_B32) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(g), "v"(h));
+            if (OP == BFI_B32) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r[i]) : "v"(g), "v"(h));
+            if (OP == LSHL_OR_B32) asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == OR3_B32) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(g), "v"(h));
+            if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == OR_B32) asm volatile("v_or_b32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == LSHLREV_B32) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r[i]));
+            if (OP == PK_ADD_I16) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == PK_ADD_I16_CLAMP) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(r[i]) : "v"(g));
+            if (OP == PK_SUB_U16_CLAMP) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(r[i]) : "v"(g));
+            if (OP == PK_LSHLREV_B16) asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(r[i]));
+            if (OP == SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == MAX_I16) asm volatile("v_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == ADD_U16) asm volatile("v_add_u16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            if (OP == BITOP3_B32) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(g), "v"(h));
+            if (OP == MIX_PKMAX_AND) {          // half of the instructions packed maxima, half plain ANDs
+                if (i & 1) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+                else asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            }
+            if (OP == MIX_PKMAX_AND_2TO1) {     // two packed per AND, roughly the tagged affine fill's mix
+                if (i % 3 == 2) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+                else asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
+            }
         }
     }
     long long t1 = clock64();
@@ -121,8 +147,14 @@ void run(const char *name) {
     hipFree(cyc);
 }
 
-int main() {
+int main(int argc, char **argv) {
 #define RUN(op) run<op>(#op)
+    if (argc > 1) {                                 // second batch only
+        RUN(AND_OR_B32); RUN(BFI_B32); RUN(LSHL_OR_B32); RUN(OR3_B32); RUN(XOR_B32); RUN(OR_B32); RUN(LSHLREV_B32);
+        RUN(PK_ADD_I16); RUN(PK_ADD_I16_CLAMP); RUN(PK_SUB_U16_CLAMP); RUN(PK_LSHLREV_B16); RUN(SUB_U32); RUN(MAX_I16);
+        RUN(ADD_U16); RUN(BITOP3_B32); RUN(MIX_PKMAX_AND); RUN(MIX_PKMAX_AND_2TO1);
+        return 0;
+    }
     RUN(PK_MAX_I16); RUN(MAX_I32); RUN(ADD_U32); RUN(ADD_F32); RUN(FMA_F32); RUN(MAX_F32); RUN(MAX3_F32);
     RUN(MAXIMUM3_F32); RUN(MAX3_I32); RUN(MIN3_U32); RUN(MED3_I32); RUN(ADD3_U32); RUN(ADD_F32_CLAMP);
     RUN(SUB_SAT_U32); RUN(ADD_I32_SAT); RUN(PK_FMA_F32); RUN(PK_ADD_F32); RUN(PK_MUL_F32); RUN(PK_MOV_B32);

@@ -297,6 +297,7 @@ public:
 
     ~Engine() {
         (void)hipSetDevice(device_);
+        if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
         release_staging();
         release_trace_scratch();
         if (d_brow_) (void)hipFree(d_brow_);
@@ -305,6 +306,13 @@ public:
             if (in_done_[s]) (void)hipEventDestroy(in_done_[s]);
             if (kernels_done_[s]) (void)hipEventDestroy(kernels_done_[s]);
             if (streams_[s]) (void)hipStreamDestroy(streams_[s]);
+        }
+        if (trace_stream_) {
+            for (int r = 0; r < 2; ++r) {
+                (void)hipEventDestroy(fill_done_[r]);
+                (void)hipEventDestroy(trace_done_[r]);
+            }
+            (void)hipStreamDestroy(trace_stream_);
         }
     }
 
@@ -479,12 +487,18 @@ public:
     // align_fill_affine_tag_kernel keeps 8 * cell + tag in int16; SW needs open scores < 0 (the tag rides on the
     // open constant) and, for the lane key, value << 4 (5) in range
     bool affine_tagged_range_ok(int alg) const {
-        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
         const int worst = std::min({sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, sc_.mismatch, 0});
         // NW: every cell is at least the path "one gap up, one gap left"; E / F sit one open below H
-        const long long lo = alg == kAlgSW ? worst
-                                           : 2ll * (std::min(sc_.open_read, 0) + std::min(sc_.open_ref, 0)) +
-                                                 (long long)(R_ + F_ + 2) * std::min({sc_.ext_read, sc_.ext_ref, 0}) + worst;
+        long long lo = alg == kAlgSW ? worst
+                                     : 2ll * (std::min(sc_.open_read, 0) + std::min(sc_.open_ref, 0)) +
+                                           (long long)(R_ + F_ + 2) * std::min({sc_.ext_read, sc_.ext_ref, 0}) + worst;
+        if (alg == kAlgNW) {        // the kernel's tilted frame: cell (p, j) carries - ext_ref * p - ext_read * j on top
+            const long long rows = (long long)plan_.geo->G * plan_.geo->K + 1, cols = F_ + 1;
+            hi += std::max(0, -sc_.ext_ref) * rows + std::max(0, -sc_.ext_read) * cols;
+            lo += std::min(0, -sc_.ext_ref) * rows + std::min(0, -sc_.ext_read) * cols;
+            if (std::abs((long long)sc_.ext_ref) * rows > 3500 || std::abs((long long)sc_.ext_read) * cols > 3500) return false;
+        }
         if (alg == kAlgSW && (sc_.open_read >= 0 || sc_.open_ref >= 0)) return false;
         const int key_bits = plan_.geo->K <= 16 ? 4 : 5;
         if (alg == kAlgSW && ((hi + 1) << key_bits) > 32000) return false;
@@ -698,7 +712,8 @@ public:
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
         const size_t have = trace_bytes_;
-        const size_t cap = std::min<size_t>(64ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
+        size_t cap = std::min<size_t>(64ull << 30, std::max<size_t>((free_b + have) / 2, 256ull << 20));
+        if (scratch_cap_mb_ > 0) cap = std::min<size_t>(cap, (size_t)scratch_cap_mb_ << 20);
         long long chunk = (long long)(cap / bytes_per_pp) * 2;
         chunk = std::max(ppb, chunk / ppb * ppb);
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
@@ -719,13 +734,38 @@ public:
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        for (long long begin = 0; begin < n; begin += chunk) {
-            const long long cnt = std::min(chunk, n - begin);
+        // Parts of the batch: the traceback of one part runs on a helper stream beside the fill of the next (the walk
+        // waits on memory at 17 % VALU issue, the fill owns the VALU).  A batch that fits the scratch in one piece is cut
+        // 7/8 + 1/8 -- the short fill covers the long walk, what stays exposed is the walk of the last eighth; a batch
+        // that needs several chunks alternates between the two halves of the scratch.
+        struct Part { long long begin, cnt, slot; int region; };
+        std::vector<Part> parts;
+        const bool overlap = !no_overlap_ && (double)n * R_ * F_ >= 1e10;
+        if (overlap && chunk >= n && n >= 16 * ppb) {
+            const long long big = std::max(ppb, n * 7 / 8 / ppb * ppb);
+            parts.push_back(Part{0, big, 0, 0});
+            parts.push_back(Part{big, n - big, big, 1});
+        } else if (overlap && chunk < n && chunk >= 4 * ppb) {
+            const long long half = chunk / 2 / ppb * ppb;
+            for (long long begin = 0, i = 0; begin < n; begin += half, ++i)
+                parts.push_back(Part{begin, std::min(half, n - begin), (i & 1) * half, (int)(i & 1)});
+        } else {
+            for (long long begin = 0; begin < n; begin += chunk) parts.push_back(Part{begin, std::min(chunk, n - begin), 0, 0});
+        }
+        const bool helper = parts.size() > 1 && overlap;
+        if (helper) ensure_trace_stream();
+        bool region_used[2] = {false, false};
+        for (const Part &part : parts) {
+            const long long begin = part.begin, cnt = part.cnt;
+            unsigned *part_ptr = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(d_ptr_) + (size_t)(part.slot / 2) * bytes_per_pp);
+            EndCell *part_ends = d_ends_ + part.slot;
+            if (helper && region_used[part.region])          // the region's previous walk must be over before it is overwritten
+                hip_check(hipStreamWaitEvent(stream, trace_done_[part.region], 0), "hipStreamWaitEvent");
             FillArgs f;
             f.reads = d_reads + (size_t)begin * R_;
             f.refs = d_refs + (size_t)begin * F_;
-            f.ptr = d_ptr_;
-            f.ends = d_ends_;
+            f.ptr = part_ptr;
+            f.ends = part_ends;
             f.n = cnt;
             f.R = R_;
             f.F = F_;
@@ -749,8 +789,8 @@ public:
             TraceArgs t{};
             t.reads = f.reads;
             t.refs = f.refs;
-            t.ptr = d_ptr_;
-            t.ends = d_ends_;
+            t.ptr = part_ptr;
+            t.ends = part_ends;
             t.rows = d_rows + (size_t)begin * 2 * AL;
             t.idx = d_idx + (size_t)begin * 4;
             t.n = cnt;
@@ -773,9 +813,31 @@ public:
             t.open_ref = f.open_ref;
             t.ext_ref = f.ext_ref;
             void *targs[] = {&t};
+            hipStream_t walk_stream = stream;
+            if (helper) {
+                hip_check(hipEventRecord(fill_done_[part.region], stream), "hipEventRecord");
+                hip_check(hipStreamWaitEvent(trace_stream_, fill_done_[part.region], 0), "hipStreamWaitEvent");
+                walk_stream = trace_stream_;
+            }
             hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
-                                      targs, 0, stream),
+                                      targs, 0, walk_stream),
                       "hipLaunchKernel(traceback_kernel)");
+            if (helper) {
+                hip_check(hipEventRecord(trace_done_[part.region], trace_stream_), "hipEventRecord");
+                region_used[part.region] = true;
+            }
+        }
+        if (helper)                                        // the call stays asynchronous on `stream`: it ends when the walks have
+            for (int r = 0; r < 2; ++r)
+                if (region_used[r]) hip_check(hipStreamWaitEvent(stream, trace_done_[r], 0), "hipStreamWaitEvent");
+    }
+
+    void ensure_trace_stream() {
+        if (trace_stream_) return;
+        hip_check(hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking), "hipStreamCreate(traceback)");
+        for (int r = 0; r < 2; ++r) {
+            hip_check(hipEventCreateWithFlags(&fill_done_[r], hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&trace_done_[r], hipEventDisableTiming), "hipEventCreate");
         }
     }
 
@@ -1159,7 +1221,7 @@ private:
             }
             if (const char *force = getenv("VALIGN_HIP_WPB")) {                 // tuning switch
                 const int wpb = atoi(force);
-                if ((wpb == 1 || wpb == 2 || wpb == 4) && p.lds.total * wpb <= kMaxBlockLds) {
+                if (wpb >= 1 && wpb <= 4 && p.lds.total * wpb <= kMaxBlockLds) {
                     p.waves_per_block = wpb;
                     best_waves = std::min(32, (kMaxBlockLds / (p.lds.total * wpb)) * wpb);
                 }
@@ -1593,6 +1655,10 @@ private:
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     bool no_fused_ = getenv("VALIGN_HIP_NO_FUSED") != nullptr;   // tuning switch: small alignment calls as fill + traceback kernels
+    bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
+    long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch
+    hipStream_t trace_stream_ = nullptr;                          // helper stream of align_device (walks beside the next fill)
+    hipEvent_t fill_done_[2] = {nullptr, nullptr}, trace_done_[2] = {nullptr, nullptr};
     std::string arch_;
     LaunchPlan plan_, latency_plan_;
     hipStream_t streams_[kSlots] = {};

@@ -1067,11 +1067,19 @@ align_fill_affine_kernel(const FillArgs args) {
 // is three bit operations and a multiply-add away.  18 packed instructions per register instead of
 // 22; the pointer stream is K dwords per lane and 4-step block (same volume as before).
 // SYM: open_read == open_ref and ext_read == ext_ref, `H + open` shared by E and F.
+// NW (no zero floor) runs in a tilted frame: every value of cell (p, j) is kept as
+//   V'(p, j) = V(p, j) - ext_ref * p - ext_read * j        (p padded row, j matrix column; times 8)
+// so that extending a gap costs nothing -- E' = max(E'(p, j-1), H'(p, j-1) + open_read - ext_read),
+// F' = max(F'(p-1, j), H'(p-1, j) + open_ref - ext_ref) -- and the diagonal term pays both extensions,
+// folded into the query profile (S - ext_ref - ext_read).  Two packed adds per register less; the pointers are
+// those of the plain frame (every candidate of a cell is shifted by the same amount), the row arg-max of
+// the end-cell rule is taken on un-tilted values (two instructions per step).
 template <int G, int K, int ALG, bool SYM>
 __global__ void __launch_bounds__(256)
 align_fill_affine_tag_kernel(const FillArgs args) {
     using geo = Geo<G, K>;
     constexpr bool LANEKEY = ALG == kAlgSW;
+    constexpr bool TILT = ALG == kAlgNW;
     constexpr int kKeyBits = K <= 16 ? 4 : 5;
     const int lane = threadIdx.x & (kWave - 1);
     const int grp = lane / G;
@@ -1079,10 +1087,12 @@ align_fill_affine_tag_kernel(const FillArgs args) {
     const int R = args.R;
     const int pad_rows = geo::kRows - R;
 
+    const int tilt_row = TILT ? -8 * args.ext_ref : 0, tilt_col = TILT ? -8 * args.ext_read : 0;
+    const int tilt_diag = tilt_row + tilt_col;
     WaveTables w;
     if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                args.wave_lds, (short)(8 * args.match + 4), (short)(8 * args.mismatch + 4), w, false,
-                                blockIdx.x, (short)4))
+                                args.wave_lds, (short)(8 * args.match + 4 + tilt_diag),
+                                (short)(8 * args.mismatch + 4 + tilt_diag), w, false, blockIdx.x, (short)(4 + tilt_diag)))
         return;
     const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
@@ -1096,15 +1106,16 @@ align_fill_affine_tag_kernel(const FillArgs args) {
     if (ALG == kAlgSW) {
         x_read = pk((short)(-8 * args.ext_read));      x_ref = pk((short)(-8 * args.ext_ref));
         o_read = pk((short)(-8 * args.open_read - 1)); o_ref = pk((short)(-8 * args.open_ref - 1));
-    } else {
-        x_read = pk((short)(8 * args.ext_read));       x_ref = pk((short)(8 * args.ext_ref));
-        o_read = pk((short)(8 * args.open_read + 1));  o_ref = pk((short)(8 * args.open_ref + 1));
+    } else {                                           // tilted frame: extensions are free, opens cost open - extend
+        x_read = x_ref = pk(0);
+        o_read = pk((short)(8 * (args.open_read - args.ext_read) + 1));
+        o_ref = pk((short)(8 * (args.open_ref - args.ext_ref) + 1));
     }
     constexpr short kMinusInf = -30000;                // multiple of 8, far below any real cell, room to saturate
     const s16x2 border_f = pk(ALG == kAlgNW ? kMinusInf : (short)0);
     s16x2 two = pk(2), sixteen = pk(16), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 3)));
-    unsigned clean_mask = 0xFFF8FFF8u, src_mask = 0x00060006u, one_mask = 0x00010001u;
-    asm volatile("" : "+v"(two), "+v"(sixteen), "+v"(fifteen), "+v"(key_mul), "+v"(clean_mask), "+v"(src_mask), "+v"(one_mask));
+    unsigned clean_mask = 0xFFF8FFF8u, src_mask = 0x00060006u, one_mask = 0x00010001u, two_mask = 0x00020002u;
+    asm volatile("" : "+v"(two), "+v"(sixteen), "+v"(fifteen), "+v"(key_mul), "+v"(clean_mask), "+v"(src_mask), "+v"(one_mask), "+v"(two_mask));
 
     auto gap_add = [](s16x2 v, s16x2 c) __attribute__((always_inline)) {
         return (ALG == kAlgSW) ? pk_sub_floor0(v, c) : pk_add_sat(v, c);
@@ -1128,7 +1139,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         short border = 0;
         if (ALG == kAlgNW)                         // column 0: a gap of i bases in the ref direction (times 8)
             border = p < pad_rows ? (short)0 : (short)(8 * (args.open_ref + (p - pad_rows) * args.ext_ref));
-        Hl[q] = pk(border);
+        Hl[q] = pk((short)(border + tilt_row * p));
         if (SYM) HOl[q] = gap_add(Hl[q], o_read);
         El[q] = border_f;
         code[q] = acc[q] = pk(0);
@@ -1152,6 +1163,18 @@ align_fill_affine_tag_kernel(const FillArgs args) {
     s16x2 h_last = Hl[K - 1], f_last = border_f;
     s16x2 up0 = pk(0);
     int j = -l;
+    // tilted frame: the all-zero row above padded row 0 reads -ext_ref * (-1) - ext_read * j in lane 0 of a group,
+    // and the tracked row's cell is un-tilted before the arg-max (per pair: its own row)
+    s16x2 top_row = pk(0), top_step = pk(0), sel_tilt = pk(0), tilt_step = pk((short)tilt_col);
+    if (TILT) {
+        if (l == 0) {
+            top_row = pk((short)(-tilt_row + tilt_col));           // column 1 at step 0
+            top_step = pk((short)tilt_col);
+            up0 = pk((short)(-tilt_row));                           // column 0: the diagonal of the first cell
+        }
+        sel_tilt = s16x2{(short)(tilt_row * (ir[0] - 1 + pad_rows) + tilt_col * (1 - l)),
+                         (short)(tilt_row * (ir[1] - 1 + pad_rows) + tilt_col * (1 - l))};
+    }
 
     unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);     // blocks8: 4-step blocks here
 
@@ -1171,7 +1194,8 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool LAST_ONLY = decltype(last_only_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        up0 = TILT ? as_pk((from_prev_lane(as_u32(h_last)) & lmask) | as_u32(top_row))
+                   : as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         const unsigned fv = from_prev_lane(as_u32(f_last));
         const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
         s16x2 S[K];
@@ -1186,7 +1210,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
             s16x2 d_cur, e_cur;
             auto pass1 = [&](int q, s16x2 &d_t, s16x2 &e_t) __attribute__((always_inline)) {
                 d_t = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                                     // tag 4: DIAG
-                const s16x2 e_ext = gap_add(El[q], x_read);                                    // bit 0 = 0: extended
+                const s16x2 e_ext = TILT ? El[q] : gap_add(El[q], x_read);                     // bit 0 = 0: extended
                 const s16x2 e_opn = SYM ? HOl[q] : gap_add(Hl[q], o_read);                     // bit 0 = 1: opened
                 e_t = pk_max(e_ext, e_opn);
                 El[q] = as_pk(as_u32(e_t) & clean_mask);
@@ -1197,20 +1221,25 @@ align_fill_affine_tag_kernel(const FillArgs args) {
             pass1(0, d_cur, e_cur);
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const s16x2 f_ext = gap_add(fcl, x_ref);
+                const s16x2 f_ext = TILT ? fcl : gap_add(fcl, x_ref);
                 const s16x2 f_t = pk_max(f_ext, ho);
                 s16x2 d_next = pk(0), e_next = pk(0);
                 if (q + 1 < K) pass1(q + 1, d_next, e_next);                 // before Hl[q] is overwritten
                 fcl = as_pk(as_u32(f_t) & clean_mask);
-                const s16x2 f_h = f_t + two;                                  // bits 2..1 = 1: from F
+                // The bit operations below are single 32-bit instructions over both halves on purpose: plain AND / OR /
+                // ADD and v_bitop3_b32 issue at twice the rate of the packed-16 and the other three-operand integer
+                // forms (tools/microbench/valu_rate2.hip); none of them carries across the halves.
+                const s16x2 f_h = as_pk(as_u32(f_t) | two_mask);              // bits 2..1 = 1: from F (bit 1 is clear in F)
                 const s16x2 h_t = pk_max(pk_max(d_cur, f_h), e_cur);
                 hc = as_pk(as_u32(h_t) & clean_mask);
                 Hl[q] = hc;
                 ho = gap_add(hc, o_ref);
                 if (SYM) HOl[q] = ho;
                 // 4-bit code: [3:2] source of H (2 DIAG, 1 F, 0 E), [1] E opened, [0] F opened
-                const unsigned src_e = (as_u32(e_cur) & one_mask) | (as_u32(h_t) & src_mask);
-                code[q] = pk_mad_u(as_pk(src_e), two, as_pk(as_u32(f_t) & one_mask));
+                const unsigned src_e = __builtin_amdgcn_bitop3_b32(as_u32(h_t), src_mask, as_u32(e_cur) & one_mask, 0xEA);    // (h & 6) | e0
+                unsigned src_e2;
+                asm("v_add_u32 %0, %1, %1" : "=v"(src_e2) : "v"(src_e));      // (the compiler would pick the half-rate shift)
+                code[q] = as_pk(__builtin_amdgcn_bitop3_b32(as_u32(f_t), one_mask, src_e2, 0xEA));                           // 2 * that | f0
                 if (ALG == kAlgSW) {
                     step_key = pk_max(step_key, pk_mad_u(hc, key_mul, row_key[q]));
                 } else {
@@ -1229,7 +1258,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
                 fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
                 rb[0] = pk_max(rb[0], step_key);
             } else {
-                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 nb = pk_max(rb[0], hs - sel_tilt);                // the tracked row's cell, un-tilted
                 const s16x2 changed = (rb[0] - nb) >> fifteen;
                 fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
                 rb[0] = nb;
@@ -1240,6 +1269,10 @@ align_fill_affine_tag_kernel(const FillArgs args) {
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], sixteen, code[q]);
         if ((t & 3) == 3) finish_block<K>(ptr_lane, t >> 2, acc);
+        if (TILT) {
+            top_row = top_row + top_step;
+            sel_tilt = sel_tilt + tilt_step;
+        }
         ++j;
         code_addr += 2;
     };
