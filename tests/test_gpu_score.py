@@ -182,7 +182,9 @@ def test_symmetric_and_asymmetric_affine_kernels(aff):
 def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
     """Symmetric affine Smith-Waterman runs on packed half floats while every value stays an integer of
     magnitude <= 2048 (150 x 13 = 1950), on int16 beyond (150 x 14 = 2100).  Perfect matches drive the
-    scores to the top of the range; both must equal the oracle."""
+    scores to the top of the range; both must equal the oracle.  The NW variant's tilted frame (gap extensions
+    free, every cell plus 3 per row and column, centred on zero) spans 1950 + 1986 here: +-1968 plus three
+    openings still fits, 2100 + 1986 does not."""
     R, F, n = 150, 500, 600
     reads, refs = synth.make_pairs(n, R, F, seed=81, sub_rate=0.0, n_run_frac=0.0, short_frac=0.0)
     noisy, _ = synth.make_pairs(n, R, F, seed=81, sub_rate=0.1, n_run_frac=0.0, short_frac=0.0)
@@ -190,12 +192,13 @@ def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
     aff = dict(open_read=-20, ext_read=-3, open_ref=-20, ext_ref=-3)
     eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(match, -11, -20, -20, **aff))
     assert eng.describe(host.SW)["score_cells"] == cells
-    assert eng.describe(host.NW)["score_cells"] == "int16"
+    assert eng.describe(host.NW)["score_cells"] == cells
     import torch
-    got = eng.score_device(host.SW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
-    exp = cpu_ref.score(host.SW, reads, refs, cpu_ref.Scoring.make(match, -11, -20, -20, **aff), threads=8, affine=True)
-    assert exp.max() == 150 * match
-    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:8]
+    for opt in (host.SW, host.NW):
+        got = eng.score_device(opt, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+        exp = cpu_ref.score(opt, reads, refs, cpu_ref.Scoring.make(match, -11, -20, -20, **aff), threads=8, affine=True)
+        assert exp.max() == 150 * match
+        assert np.array_equal(got, exp), (opt, np.nonzero(got != exp)[0][:8])
     eng.close()
 
 
@@ -290,4 +293,28 @@ def test_small_calls_run_on_the_pinned_staging_directly(monkeypatch):
         big_r, big_f = np.tile(reads, (40, 1)), np.tile(refs, (40, 1))
         assert np.array_equal(eng.score_host(0, big_r, big_f, threads=4), np.tile(exp[0], 40))
         assert eng.describe(0, n)["direct_call"] == 0
+        eng.close()
+
+
+@pytest.mark.parametrize("gap,cells", [(-3, "f16"), (-10, "int16"), (-15, "int32")])
+def test_nw_frame_keeps_inside_its_cell_range(gap, cells):
+    """The NW score kernels keep cell (p, j) plus |gap| * (p + j) (tilted frame: gap steps cost nothing, the diagonal
+    pays for both).  With a forced 64 x 32 geometry (2048 padded rows) that adds up to |gap| * 2350 at the far corner:
+    half floats while the centred range stays inside +-2048, int16 while it stays inside the int16 range, int32 cells
+    (strip path) beyond -- and the oracle's scores every time."""
+    import torch
+    R, F, n = 100, 300, 300
+    reads, refs = synth.make_pairs(n, R, F, seed=123, indel_rate=0.02, n_run_frac=0.02, short_frac=0.05)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, gap, gap), group_lanes=64, rows_per_lane=32)
+    if gap == -3:        # 200 + 3 * 2350 = 7250: not even the centred half-float range -> int16 at this geometry
+        cells = "int16"
+    assert eng.describe(host.NW)["score_cells"] == cells
+    got = eng.score_device(host.NW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+    assert np.array_equal(got, cpu_ref.score(host.NW, reads, refs, cpu_ref.Scoring.make(2, -1, gap, gap), threads=8))
+    eng.close()
+    if gap == -3:        # the engine's own geometry (7 x 16 = 112 rows): 200 + 3 * 414 centred = +-721 -> half floats
+        eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, gap, gap))
+        assert eng.describe(host.NW)["score_cells"] == "f16"
+        got = eng.score_device(host.NW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+        assert np.array_equal(got, cpu_ref.score(host.NW, reads, refs, cpu_ref.Scoring.make(2, -1, gap, gap), threads=8))
         eng.close()

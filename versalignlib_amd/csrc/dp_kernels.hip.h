@@ -451,6 +451,14 @@ constexpr int kGapSymF16 = 6;
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step
 
+// Half-float NW kernels: the constant their tilted frame is centred by -- half of the largest value a cell of the
+// frame can take (best possible score plus what row and column add at the far corner).
+__host__ __device__ inline int nw_frame_centre(int R, int F, int rows, int match, int mismatch, int tilt_row, int tilt_col) {
+    const int best = match > mismatch ? match : mismatch;
+    const int top = (R < F ? R : F) * (best > 0 ? best : 0);
+    return (top + tilt_row * (rows + 1) + tilt_col * (F + 1)) / 2;
+}
+
 template <int G, int K, int ALG, int GAPS>
 __global__ void __launch_bounds__(256)
 score_kernel(const ScoreArgs args) {
@@ -487,11 +495,34 @@ score_kernel(const ScoreArgs args) {
     // (kGapSymF16: S - g, also for the rows / bases that score 0)
     // (kGapSymF16: NW S - g, also for the rows / bases that score 0; SW S * 2^-10)
     constexpr bool LINF16_SW = LINF16 && ALG == kAlgSW, LINF16_NW = LINF16 && ALG == kAlgNW;
-    const int fold = LINF16_NW ? -(int)args.gap_ref : 0;
+    // The NW variant (no zero floor) runs in a tilted frame: cell (p, j) -- p padded row, j matrix column -- is kept as
+    //   V'(p, j) = V(p, j) - g_ref * p - g_read * j          (g: the gap score, or the extension score with affine gaps)
+    // In it a gap step (an extension) costs nothing -- "up + g" and "left + g" are simply the neighbours' registers,
+    // E' = max(E', H' + open - ext), F' likewise -- and the diagonal step pays both, folded into the query profile
+    // (S - g_ref - g_read, also for the rows / bases that score 0).  One or two packed instructions per register less in
+    // every recurrence; results are taken out of the frame where they are read (last row: per step, last column: once).
+    constexpr bool TILT = ALG == kAlgNW;
+    constexpr bool HALF = F16 || LINF16;          // cells are half floats (bit patterns in the s16x2 containers)
+    const int tilt_row = TILT ? -(int)(AFFINE ? args.ext_ref : args.gap_ref) : 0;
+    const int tilt_col = TILT ? -(int)(AFFINE ? args.ext_read : args.gap_read) : 0;
+    const int fold = tilt_row + tilt_col;
+    // Half-float cells are exact up to 2048 in magnitude and the frame only ever adds: a constant taken off every cell
+    // (borders start at -centre, results get it back) puts the sweep's value range [~0, top + tilt] around zero.  The
+    // host checks the range with the same formula (Engine::half_float_exact).
+    const int centre = (HALF && TILT) ? nw_frame_centre(args.R, F_batch, G * K, args.match, args.mismatch, tilt_row, tilt_col) : 0;
     const float unit = LINF16_SW ? 1.0f / 1024.0f : 1.0f;
-    const short s_match = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)(((int)args.match + fold) * unit)) : args.match;
-    const short s_mismatch = (F16 || LINF16) ? __builtin_bit_cast(short, (_Float16)(((int)args.mismatch + fold) * unit)) : args.mismatch;
-    const short s_zero = LINF16_NW ? __builtin_bit_cast(short, (_Float16)fold) : (short)0;
+    auto cell = [](int v) __attribute__((always_inline)) {           // an integer in the cell format of this kernel, both halves
+        return HALF ? pk(__builtin_bit_cast(short, (_Float16)v)) : pk((short)v);
+    };
+    auto cell_add = [](s16x2 a, s16x2 b) __attribute__((always_inline)) {
+        return HALF ? __builtin_bit_cast(s16x2, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b)) : a + b;
+    };
+    auto cell_sub = [](s16x2 a, s16x2 b) __attribute__((always_inline)) {
+        return HALF ? __builtin_bit_cast(s16x2, __builtin_bit_cast(f16x2, a) - __builtin_bit_cast(f16x2, b)) : a - b;
+    };
+    const short s_match = HALF ? __builtin_bit_cast(short, (_Float16)(((int)args.match + fold) * unit)) : (short)(args.match + fold);
+    const short s_mismatch = HALF ? __builtin_bit_cast(short, (_Float16)(((int)args.mismatch + fold) * unit)) : (short)(args.mismatch + fold);
+    const short s_zero = HALF ? __builtin_bit_cast(short, (_Float16)fold) : (short)fold;
     if (!wave_setup<G, K, false>(reads, refs, n_pairs, args.R, F_batch, args.prof_area, args.refc_stride,
                                  args.wave_lds, s_match, s_mismatch, w, false, block, s_zero))
         return;
@@ -511,16 +542,16 @@ score_kernel(const ScoreArgs args) {
         g_read = pk((short)-args.gap_read);   g_ref = pk((short)-args.gap_ref);
         o_read = pk((short)-args.open_read);  e_read = pk((short)-args.ext_read);
         o_ref = pk((short)-args.open_ref);    e_ref = pk((short)-args.ext_ref);
-    } else {                       // signed addends
-        g_read = pk(args.gap_read);   g_ref = pk(args.gap_ref);
-        o_read = pk(args.open_read);  e_read = pk(args.ext_read);
-        o_ref = pk(args.open_ref);    e_ref = pk(args.ext_ref);
+    } else {                       // tilted frame: gap steps / extensions are free, an opening costs open - extend
+        g_read = g_ref = e_read = e_ref = pk(0);
+        o_read = pk((short)(args.open_read - args.ext_read));
+        o_ref = pk((short)(args.open_ref - args.ext_ref));
     }
     // gap matrices start at minus infinity in the NW variant (half floats have the real thing: 0xFC00)
     const s16x2 border_f = pk(ALG == kAlgNW ? (F16 ? (short)0xFC00 : kNegInf) : (short)0);
     // half-float recurrence: signed addends (open, extend <= 0)
-    const _Float16 open_h = (_Float16)(int)args.open_ref, ext_h = (_Float16)(int)args.ext_ref;
-    const _Float16 open_rd = (_Float16)(int)args.open_read, ext_rd = (_Float16)(int)args.ext_read;
+    const _Float16 open_h = (_Float16)(int)(TILT ? args.open_ref - args.ext_ref : args.open_ref), ext_h = (_Float16)(int)args.ext_ref;
+    const _Float16 open_rd = (_Float16)(int)(TILT ? args.open_read - args.ext_read : args.open_read), ext_rd = (_Float16)(int)args.ext_read;
     const f16x2 o_half = f16x2{open_h, open_h}, e_half = f16x2{ext_h, ext_h}, zero_half = f16x2{(_Float16)0, (_Float16)0};
     const f16x2 o_read_half = f16x2{open_rd, open_rd}, e_read_half = f16x2{ext_rd, ext_rd};
 
@@ -528,19 +559,28 @@ score_kernel(const ScoreArgs args) {
     // H - open of the previous column, which feeds E of this column (and, within a column, F of
     // the next row), so the subtract is done once per cell instead of twice.
     s16x2 Hl[K], El[K], HOl[K];
-    const s16x2 ho_border = (ALG == kAlgSW) ? pk(0)               // border H (= 0) minus open
-                                            : (F16 ? pk(__builtin_bit_cast(short, (_Float16)(int)args.open_ref)) : o_ref);
-    // kGapSymF16 keeps H + g: the zero border is g
-    const s16x2 lin_border = LINF16_NW ? pk(__builtin_bit_cast(short, (_Float16)(int)args.gap_ref)) : pk(0);
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-        Hl[q] = lin_border;
+        Hl[q] = cell(tilt_row * (l * K + q) - centre);          // column 0: the zero border (in the NW frame: what the row adds)
         El[q] = border_f;
-        HOl[q] = ho_border;
+        // border H plus (SW: minus) open
+        HOl[q] = (ALG == kAlgSW) ? pk(0) : (F16 ? cell_add(Hl[q], pk(__builtin_bit_cast(short, open_h))) : Hl[q] + o_ref);
     }
-    s16x2 up0 = lin_border, h_last = lin_border, f_last = border_f, best = pk(0);
-    s16x2 row_best = LINF16_NW ? pk((short)0xFC00) : pk(0);     // kGapSymF16 (NW): maximum of H + g, starts at -inf
+    s16x2 up0 = pk(0), h_last = Hl[K - 1], f_last = border_f, best = pk(0);
+    s16x2 row_best = pk(0);
     int j = -l;                                                  // this lane's column at step t
+    // NW frame: the all-zero row above padded row 0, as the group leader sees it (row -1, column 1 at step 0, one
+    // column on per step), and what the last padded row adds at this lane's column (taken off before the row maximum)
+    s16x2 top_row = pk(0), top_step = pk(0), row_tilt = pk(0);
+    const s16x2 col_step = cell(tilt_col);
+    if (TILT) {
+        if (l == 0) {
+            top_row = cell(-tilt_row + tilt_col - centre);
+            top_step = col_step;                       // (stays zero in the other lanes: it is OR-ed into their row above)
+            up0 = cell(-tilt_row - centre);            // row -1, column 0: the diagonal of the first cell
+        }
+        row_tilt = cell(tilt_row * (G * K - 1) + tilt_col * (1 - l) - centre);
+    }
 
     // LDS fetches run one step ahead of the arithmetic (every lane, every step: the code arrays are
     // padded): on entry to step t the raw profile dwords of step t and the slab numbers of step t+1
@@ -575,14 +615,12 @@ score_kernel(const ScoreArgs args) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int TRACK = decltype(track_tag)::value;
         const s16x2 diag0 = up0;
-        if (LINF16_NW) {           // the group leader's "row above" is the border, g in the H + g form
-            const unsigned above = from_prev_lane(as_u32(h_last));     // every lane takes part: a DPP read of a
-            up0 = as_pk(l == 0 ? as_u32(lin_border) : above);          // lane masked off by the select returns 0
-        } else if (G == 16) {      // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
+        if (G == 16) {             // row_shr:1 is exactly "previous lane of my 16-lane group, else 0"
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
         } else {
             up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         }
+        if (TILT) up0 = as_pk(as_u32(up0) | as_u32(top_row));         // (zero in every lane but the group leader)
         s16x2 fup0 = border_f;
         if (AFFINE) {
             const unsigned fv = from_prev_lane(as_u32(f_last));
@@ -635,22 +673,19 @@ score_kernel(const ScoreArgs args) {
                 h_last = bits(h);
                 f_last = bits(up_c);
             } else if (LINF16) {
-                // hg = max3(hg_diag + (S - g), hg_left, hg_up) + g, everything in the H + g form
+                // NW frame: h = max3(diag + S', left, up) -- perm, add, max3: three packed instructions per register
                 auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
-                const _Float16 gh = (_Float16)(int)args.gap_ref;
-                const f16x2 g_half = f16x2{gh, gh};
-                f16x2 hg = hf(up0);
+                f16x2 h = hf(up0);
                 f16x2 d_cur = hf(diag0) + hf(S[0]);
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     f16x2 d_next = d_cur;
                     if (q + 1 < K) d_next = hf(Hl[q]) + hf(S[q + 1]);       // before Hl[q] is overwritten
-                    const f16x2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, hf(Hl[q])), hg);
-                    hg = m + g_half;
-                    Hl[q] = __builtin_bit_cast(s16x2, hg);
+                    h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, hf(Hl[q])), h);
+                    Hl[q] = __builtin_bit_cast(s16x2, h);
                     d_cur = d_next;
                 }
-                h_last = __builtin_bit_cast(s16x2, hg);
+                h_last = __builtin_bit_cast(s16x2, h);
             } else if (F16) {
                 // Registers hold two half floats (bit patterns in the s16x2 containers).  pass1(q) -- diag + S
                 // and E of row q, which only need the previous column -- is written between the links of the
@@ -661,7 +696,7 @@ score_kernel(const ScoreArgs args) {
                 auto pass1 = [&](int q, f16x2 &d, f16x2 &e) __attribute__((always_inline)) {
                     d = hf(q == 0 ? diag0 : Hl[q - 1]) + hf(S[q]);
                     const f16x2 e_open = F16SYM ? hf(HOl[q]) : hf(Hl[q]) + o_read_half;
-                    e = __builtin_elementwise_maximum(hf(El[q]) + e_read_half, e_open);
+                    e = __builtin_elementwise_maximum(TILT ? hf(El[q]) : hf(El[q]) + e_read_half, e_open);
                     if (ALG == kAlgSW) e = __builtin_elementwise_maximum(e, zero_half);     // folds into one max3: floors the cell
                     El[q] = bits(e);
                 };
@@ -672,7 +707,7 @@ score_kernel(const ScoreArgs args) {
                 pass1(0, d_cur, e_cur);
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
-                    f = __builtin_elementwise_maximum(f + e_half, ho);
+                    f = __builtin_elementwise_maximum(TILT ? f : f + e_half, ho);
                     f16x2 d_next = zero_half, e_next = zero_half;
                     if (q + 1 < K) pass1(q + 1, d_next, e_next);        // before Hl[q] is overwritten
                     h = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, e_cur), f);
@@ -702,7 +737,7 @@ score_kernel(const ScoreArgs args) {
                     const s16x2 x = pk_max(Hl[q], h);
                     s16x2 d_next = pk(0);
                     if (q + 1 < K) d_next = Hl[q] + S[q + 1];
-                    const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x + g_ref;
+                    const s16x2 y = (ALG == kAlgSW) ? pk_sub_floor0(x, g_ref) : x;          // (NW frame: the gap step is free)
                     if (ALG == kAlgSW && TRACK == kTrackAll) best = pk_max(best, d_cur);   // max = a diagonal arrival
                     if (ALG == kAlgSW && TRACK == kTrackPair) best = pk_max(best, x);
                     h = pk_max(d_cur, y);
@@ -720,15 +755,15 @@ score_kernel(const ScoreArgs args) {
                     const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
                     s16x2 e;
                     if (AFFSYM) {
-                        e = pk_max((ALG == kAlgSW) ? pk_sub_floor0(El[q], e_read) : pk_add_sat(El[q], e_read), HOl[q]);
+                        e = pk_max((ALG == kAlgSW) ? pk_sub_floor0(El[q], e_read) : El[q], HOl[q]);
                         El[q] = e;
                     } else if (AFFINE) {
                         e = (ALG == kAlgSW)
                                 ? pk_max(pk_sub_floor0(El[q], e_read), pk_sub_floor0(Hl[q], o_read))
-                                : pk_max(pk_add_sat(El[q], e_read), pk_add_sat(Hl[q], o_read));
+                                : pk_max(El[q], pk_add_sat(Hl[q], o_read));
                         El[q] = e;
                     } else {
-                        e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;
+                        e = (ALG == kAlgSW) ? pk_sub_floor0(Hl[q], g_read) : Hl[q];
                     }
                     if (ALG == kAlgSW) best = pk_max(best, d);
                     return pk_max(d, e);
@@ -740,12 +775,12 @@ score_kernel(const ScoreArgs args) {
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     if (AFFSYM) {
-                        f = pk_max((ALG == kAlgSW) ? pk_sub_floor0(f, e_ref) : pk_add_sat(f, e_ref), ho);
+                        f = pk_max((ALG == kAlgSW) ? pk_sub_floor0(f, e_ref) : f, ho);
                     } else if (AFFINE) {
                         f = (ALG == kAlgSW) ? pk_max(pk_sub_floor0(f, e_ref), pk_sub_floor0(h, o_ref))
-                                            : pk_max(pk_add_sat(f, e_ref), pk_add_sat(h, o_ref));
+                                            : pk_max(f, pk_add_sat(h, o_ref));
                     } else {
-                        f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h + g_ref;
+                        f = (ALG == kAlgSW) ? pk_sub_floor0(h, g_ref) : h;
                     }
                     s16x2 m_next = pk(0);
                     if (q + 1 < K) m_next = pass1(q + 1);        // before Hl[q] is overwritten
@@ -761,10 +796,15 @@ score_kernel(const ScoreArgs args) {
                 f_last = f;
             }
             if (ALG == kAlgNW) {
-                if (F16 || LINF16) row_best = __builtin_bit_cast(s16x2, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, row_best),
-                                                                                             __builtin_bit_cast(f16x2, h_last)));
-                else row_best = pk_max(row_best, h_last);
+                const s16x2 last = cell_sub(h_last, row_tilt);             // the last padded row's cell, out of the frame
+                if (HALF) row_best = __builtin_bit_cast(s16x2, __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, row_best),
+                                                                                      __builtin_bit_cast(f16x2, last)));
+                else row_best = pk_max(row_best, last);
             }
+        }
+        if (TILT) {
+            top_row = cell_add(top_row, top_step);
+            row_tilt = cell_add(row_tilt, col_step);
         }
         ++j;
         code_addr += 2;
@@ -801,19 +841,13 @@ score_kernel(const ScoreArgs args) {
     if (LINF16_SW) {
         const f16x2 b = __builtin_bit_cast(f16x2, best);
         res = s16x2{(short)(int)((float)b.x * 1024.0f), (short)(int)((float)b.y * 1024.0f)};
-    } else if (LINF16) {          // back from H + g: max(0, last column, last row) = max(0, max(...) - g)
-        f16x2 b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk((short)0xFC00));
-#pragma unroll
-        for (int q = 0; q < K; ++q) b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, Hl[q]));
-        const _Float16 gh = (_Float16)(int)args.gap_ref;
-        b = __builtin_elementwise_maximum(b - f16x2{gh, gh}, f16x2{(_Float16)0, (_Float16)0});
-        res = s16x2{(short)(int)b.x, (short)(int)b.y};
-    } else if (F16) {
+    } else if (HALF) {
         f16x2 b = __builtin_bit_cast(f16x2, best);
-        if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column)
+        if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column), out of the frame
             b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk(0));
 #pragma unroll
-            for (int q = 0; q < K; ++q) b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, Hl[q]));
+            for (int q = 0; q < K; ++q)
+                b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, cell_sub(Hl[q], cell(tilt_row * (l * K + q) + tilt_col * F - centre))));
             b = __builtin_elementwise_maximum(b, f16x2{(_Float16)0, (_Float16)0});
         }
         res = s16x2{(short)(int)b.x, (short)(int)b.y};
@@ -821,11 +855,10 @@ score_kernel(const ScoreArgs args) {
         res = best;
     } else {
         // last column: every lane froze at column F-1; last row: last register of lane G-1
-        s16x2 col = Hl[0];
+        s16x2 col = l == G - 1 ? row_best : pk(0);
 #pragma unroll
-        for (int q = 1; q < K; ++q) col = pk_max(col, Hl[q]);
-        res = pk_max(col, l == G - 1 ? row_best : pk(0));
-        res = pk_max(res, pk(0));
+        for (int q = 0; q < K; ++q) col = pk_max(col, Hl[q] - cell(tilt_row * (l * K + q) + tilt_col * F - centre));
+        res = pk_max(col, pk(0));
     }
 #pragma unroll
     for (int d = G / 2; d >= 1; d >>= 1)

@@ -356,7 +356,7 @@ public:
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;          // reference: unsupported mode is a silent no-op
         hip_check(hipSetDevice(device_), "hipSetDevice");
-        if (score_width_ == 16) check_int16_range(alg);
+        if (score_width_ == 16) check_int16_range(alg, true);
         const bool wide = score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg));
         if (plan_.long_mode || wide) {      // int32 cells exist on the strip path only
             score_long_device(alg, n, d_reads, d_refs, d_scores, stream, wide);
@@ -412,10 +412,10 @@ public:
         int gaps;
         if (sc_.affine) {
             gaps = (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_) ? kGapAffineSym : kGapAffine;
-            if (!no_f16_ && half_float_exact(alg, R, F)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
+            if (!no_f16_ && half_float_exact(alg, R, F, plan.geo->G * plan.geo->K)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
-            if (gaps == kGapSym && !no_f16_ && (alg == kAlgNW ? half_float_exact(alg, R, F) : half_float_unit_exact(R, F)))
+            if (gaps == kGapSym && !no_f16_ && (alg == kAlgNW ? half_float_exact(alg, R, F, plan.geo->G * plan.geo->K) : half_float_unit_exact(R, F)))
                 gaps = kGapSymF16;
         }
         const void *fn = plan.geo->kernel[alg][gaps];
@@ -518,9 +518,9 @@ public:
     const char *score_cell_format(int alg) const {
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
-        if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_)) return "f16";
+        if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K)) return "f16";
         if (!plan_.long_mode && !sc_.affine && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ &&
-            (alg == kAlgNW ? half_float_exact(alg, R_, F_) : half_float_unit_exact(R_, F_)))
+            (alg == kAlgNW ? half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K) : half_float_unit_exact(R_, F_)))
             return "f16";
         return "int16";
     }
@@ -528,12 +528,19 @@ public:
     // Every cell of an R x F sweep and everything added to it stays an integer of magnitude <= 2048:
     // exact in half floats (kGapAffineSymF16 / kGapAffineF16).  SW cells are >= 0; cells of the NW
     // variant are bounded below by the cheaper border path (as in check_int16_range).
-    bool half_float_exact(int alg, int R, int F) const {
+    // NW: plus what the kernels' tilted frame adds to a cell of a sweep of `rows` padded rows (score_kernel).
+    bool half_float_exact(int alg, int R, int F, int rows) const {
         const long long top = (long long)std::min(R, F) * std::max({sc_.match, sc_.mismatch, 0});
-        const long long slack = std::max({std::abs(sc_.match), std::abs(sc_.mismatch), std::abs(sc_.open_read),
-                                          std::abs(sc_.ext_read), std::abs(sc_.open_ref), std::abs(sc_.ext_ref)});
-        const long long bottom = alg == kAlgSW ? 0 : (long long)(std::min(R, F) + 2) * slack;
-        return top + 2 * slack <= 2048 && bottom + 2 * slack <= 2048 && slack <= 1024;
+        long long slack = std::max({std::abs(sc_.match), std::abs(sc_.mismatch), std::abs(sc_.open_read),
+                                    std::abs(sc_.ext_read), std::abs(sc_.open_ref), std::abs(sc_.ext_ref)});
+        if (alg == kAlgSW) return top + 2 * slack <= 2048 && slack <= 1024;
+        // NW frame: H' of cell (p, j) is at least what its row or its column adds (the border path along the other axis
+        // is free there) less one opening, at most top + the far corner's tilt; E' / F' sit at most one opening below H'.
+        // The kernel centres that range on zero (nw_frame_centre, same formula).
+        if (!sc_.affine) slack = std::max<long long>(slack, std::max(std::abs(sc_.gap_read), std::abs(sc_.gap_ref)));
+        const long long span = nw_tilt_span(rows, F);
+        const long long centre = (top + span) / 2;
+        return span < 30000 && (top + span - centre) + 3 * slack <= 2048 && centre + 3 * slack <= 2048 && slack <= 512;
     }
 
     // kGapSymF16 for Smith-Waterman scales every value by 2^-10 and floors with the [0, 1] clamp of the
@@ -546,17 +553,33 @@ public:
 
     // int16 DP cells: the reference wraps silently.  Scores switch to int32 cells on the strip path
     // where they could; alignments (int16 only) are refused.
+    // The NW score kernels keep cell (p, j) plus -g_ref * p - g_read * j (g: gap / extension scores, <= 0): the most that
+    // adds over a sweep of `rows` padded rows and F columns.
+    long long nw_tilt_span(int rows, int F) const {
+        const long long per_row = -(long long)(sc_.affine ? sc_.ext_ref : sc_.gap_ref);
+        const long long per_col = -(long long)(sc_.affine ? sc_.ext_read : sc_.gap_read);
+        return per_row * (rows + 1) + per_col * (F + 1);
+    }
+    int widest_sweep_rows() const {
+        int rows = 0;
+        if (!plan_.long_mode && plan_.geo) rows = plan_.geo->G * plan_.geo->K;
+        if (latency_plan_.geo && !latency_plan_.long_mode) rows = std::max(rows, latency_plan_.geo->G * latency_plan_.geo->K);
+        return rows;
+    }
+
     bool int16_range_ok(int alg) const {
         try {
-            check_int16_range(alg);
+            check_int16_range(alg, true);
             return true;
         } catch (const std::runtime_error &) {
             return false;
         }
     }
 
-    void check_int16_range(int alg) const {
-        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+    // score_path: score_alignments' register sweep (the NW variant's tilted frame counts)
+    void check_int16_range(int alg, bool score_path = false) const {
+        long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        if (score_path && alg == kAlgNW && !plan_.long_mode) hi += nw_tilt_span(widest_sweep_rows(), F_);
         const int worst_gap = std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, 0});
         // SW cells are >= 0; NW-variant score cells are bounded below by the cheaper border path
         const long long lo = alg == kAlgSW ? (long long)std::min(sc_.mismatch, 0) + worst_gap
