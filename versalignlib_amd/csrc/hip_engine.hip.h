@@ -506,8 +506,10 @@ public:
     }
 
     // align_fill_tag_kernel keeps 4 * cell + tag in int16
-    bool tagged_range_ok(int alg) const {
-        const long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+    bool tagged_range_ok(int alg, int rows) const {     // rows: padded rows of the sweep that would run
+        long long hi = (long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1;
+        if (alg == kAlgNW && !sse_policy_)           // the kernel's tilted frame: every cell plus -gap_ref * p - gap_read * j
+            hi += (long long)-sc_.gap_ref * (rows + 1) + (long long)-sc_.gap_read * (F_ + 1);
         const int worst = std::min({sc_.gap_read, sc_.gap_ref, sc_.mismatch, 0});
         const long long lo = alg == kAlgSW ? worst : (long long)(R_ + F_ + 2) * worst;      // H(i,j) >= i gf + j gr
         if (alg == kAlgSW && !sse_policy_ && sc_.gap_ref >= 0) return false;
@@ -746,7 +748,7 @@ public:
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
         // linear gaps, Default tie-breaks: the pointer rides in the low bits of the cell where 4x the cell
         // range still fits int16 (and, for SW, gap_ref < 0); otherwise the equality-test kernels
-        const bool tagged = !sc_.affine && !no_tag_ && tagged_range_ok(alg);        // (both tie-break policies)
+        const bool tagged = !sc_.affine && !no_tag_ && tagged_range_ok(alg, G * K);        // (both tie-break policies)
         // SW: one (value, row) key per lane instead of a first-arg-max per row where value << 4 (5 bits of
         // row for more than 16 rows per lane) still fits int16
         const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
@@ -868,7 +870,7 @@ public:
     // shape / scoring has no fused kernel (the caller takes the three-kernel path).
     bool align_fused(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows, short *d_idx,
                      hipStream_t stream) {
-        if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg)) return false;
+        if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg, 256)) return false;     // (256: the tallest fused geometry)
         try {
             check_int16_range(alg);
         } catch (const std::runtime_error &) {

@@ -612,9 +612,17 @@ align_fill_tag_kernel(const FillArgs args) {
 
     WaveTables w;
     constexpr int kDiagTag = SSE ? 3 : 2;
+    // NW, default tie-breaks: the tilted frame of score_kernel -- cell (p, j) plus -gap_ref * p - gap_read * j (times 4) --
+    // in which a gap step costs nothing: LEFT is the previous column's clean register as it stands (tag 0), UP the clean
+    // cell of the row above with bit 0 set (one full-rate bit operation instead of a packed add each), the diagonal pays
+    // both gap scores through the query profile.  Every candidate of a cell is shifted alike: same pointers.
+    constexpr bool TILT = ALG == kAlgNW && !SSE;
+    const int tilt_row = TILT ? -4 * args.gap_ref : 0, tilt_col = TILT ? -4 * args.gap_read : 0;
+    const int tilt_diag = tilt_row + tilt_col;
     if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                args.wave_lds, (short)(4 * args.match + kDiagTag), (short)(4 * args.mismatch + kDiagTag), w, SSE,
-                                blockIdx.x, (short)(SSE ? 0 : 2)))
+                                args.wave_lds, (short)(4 * args.match + kDiagTag + tilt_diag),
+                                (short)(4 * args.mismatch + kDiagTag + tilt_diag), w, SSE,
+                                blockIdx.x, (short)((SSE ? 0 : 2) + tilt_diag)))
         return;
     const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
@@ -629,8 +637,8 @@ align_fill_tag_kernel(const FillArgs args) {
     const s16x2 g_read = pk(kUnsignedGaps ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read + (SSE ? 2 : 0)));
     const s16x2 g_ref = pk(kUnsignedGaps ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
     s16x2 four = pk(4), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 2)));     // cells are 4 * H already
-    unsigned tag_mask = 0x00030003u;
-    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul));
+    unsigned tag_mask = 0x00030003u, clean4_mask = 0xFFFCFFFCu, up_mask = 0x00010001u;
+    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul), "+v"(clean4_mask), "+v"(up_mask));
 
     int ir[2], jr[2];
 #pragma unroll
@@ -652,7 +660,7 @@ align_fill_tag_kernel(const FillArgs args) {
         short border = 0;
         if (ALG == kAlgNW)                         // column 0 of the NW variant: i * gap_ref, i 1-based (scaled)
             border = p < pad_rows ? (short)0 : (short)(4 * (p - pad_rows + 1) * args.gap_ref);
-        Hl[q] = pk(border);
+        Hl[q] = pk((short)(border + tilt_row * p));
         tag[q] = pk(0);
         acc[q] = pk(0);
         if (ALG == kAlgSW) {
@@ -680,6 +688,18 @@ align_fill_tag_kernel(const FillArgs args) {
     s16x2 h_last = Hl[K - 1];
     s16x2 up0 = pk(0);
     int j = -l;
+    // tilted frame: the all-zero row above padded row 0 as the group leader sees it (one column on per step), and what
+    // the tracked row of each pair adds at this lane's column (taken off before the row arg-max)
+    s16x2 top_row = pk(0), top_step = pk(0), sel_tilt = pk(0), tilt_step = pk((short)tilt_col);
+    if (TILT) {
+        if (l == 0) {
+            top_row = pk((short)(-tilt_row + tilt_col));
+            top_step = pk((short)tilt_col);
+            up0 = pk((short)(-tilt_row));
+        }
+        sel_tilt = s16x2{(short)(tilt_row * (ir[0] - 1 + pad_rows) + tilt_col * (1 - l)),
+                         (short)(tilt_row * (ir[1] - 1 + pad_rows) + tilt_col * (1 - l))};
+    }
 
     // FUSED: the wave's pointer stream lives in LDS behind its tables (same layout, wave 0 of its own little scratch)
     const FusedLds<G, K> fused = fused_lds<G, K>(args.wave_lds, R, args.F, args.blocks8);
@@ -711,6 +731,7 @@ align_fill_tag_kernel(const FillArgs args) {
         } else {
             up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
         }
+        if (TILT) up0 = as_pk(as_u32(up0) | as_u32(top_row));         // (zero in every lane but the group leader)
         s16x2 S[K];
         merge_profile<K>(pa, pb, S);
         lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
@@ -723,10 +744,11 @@ align_fill_tag_kernel(const FillArgs args) {
             // is needed, so it is computed one row ahead, between the links of the dependent chain
             auto pass1 = [&](int q) __attribute__((always_inline)) -> s16x2 {
                 const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                               // tag 2
-                const s16x2 e = kUnsignedGaps ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read;      // tag 0 (SSE: 2)
+                const s16x2 e = TILT ? Hl[q] : (kUnsignedGaps ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read);      // tag 0 (SSE: 2)
                 return pk_max(d, e);
             };
             s16x2 h = up0;
+            s16x2 f_tilt = as_pk(as_u32(up0) | up_mask);           // TILT: the clean cell above, tagged UP
             s16x2 hs = pk(0);
             s16x2 h_prev = pk(0);
             // arg-max bookkeeping of the previous row sits between the links of the dependent chain
@@ -752,13 +774,14 @@ align_fill_tag_kernel(const FillArgs args) {
             s16x2 m_cur = pass1(0);
 #pragma unroll
             for (int q = 0; q < K; ++q) {
-                const s16x2 f = kUnsignedGaps ? pk_sub_floor0(h, g_ref) : h + g_ref;                 // tag 1
+                const s16x2 f = TILT ? f_tilt : (kUnsignedGaps ? pk_sub_floor0(h, g_ref) : h + g_ref);                 // tag 1
                 s16x2 m_next = pk(0);
                 if (q + 1 < K) m_next = pass1(q + 1);          // before Hl[q] is overwritten
                 s16x2 ht = pk_max(m_cur, f);
                 if (SSE && ALG == kAlgSW) ht = pk_max(ht, pk(0));              // the floor is START (tag 0)
                 if (q > 0) finish_row(q - 1, h_prev);
                 tag[q] = as_pk(as_u32(ht) & tag_mask);
+                if (TILT) f_tilt = as_pk(__builtin_amdgcn_bitop3_b32(as_u32(ht), clean4_mask, up_mask, 0xEA));   // (ht & ~3) | 1
                 h = as_pk(as_u32(ht) & ~tag_mask);
                 Hl[q] = h;
                 h_prev = h;
@@ -774,7 +797,7 @@ align_fill_tag_kernel(const FillArgs args) {
                 rb[0] = pk_max(rb[0], step_key);
             }
             if (ALG == kAlgNW) {
-                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 nb = pk_max(rb[0], TILT ? hs - sel_tilt : hs);    // the tracked row's cell, out of the frame
                 const s16x2 changed = (rb[0] - nb) >> fifteen;
                 fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
                 rb[0] = nb;
@@ -784,6 +807,10 @@ align_fill_tag_kernel(const FillArgs args) {
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = pk_mad_u(acc[q], four, tag[q]);
         if ((t & 7) == 7) finish_block<K>(ptr_lane, t >> 3, acc);
+        if (TILT) {
+            top_row = top_row + top_step;
+            sel_tilt = sel_tilt + tilt_step;
+        }
         ++j;
         code_addr += 2;
     };
