@@ -432,3 +432,27 @@ def test_tracebacks_beside_the_next_fill(monkeypatch, cap_mb, overlap):
         erows, eidx = cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3), threads=8)
         assert np.array_equal(idx[0].cpu().numpy(), eidx) and np.array_equal(rows[0].cpu().numpy(), erows)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,F,match,prof_key", [(150, 500, 2, True), (150, 500, 3, True), (150, 500, 4, False), (300, 600, 2, False)])
+def test_sw_end_cell_key_in_the_profile_or_computed(monkeypatch, R, F, match, prof_key):
+    """Smith-Waterman alignments pick the row-major first maximum from one key per lane (value, then earlier row).
+    Where 64x the cell range fits int16 (min(R, F) * match <= 497) the key rides in the query profile; beyond, and with
+    VALIGN_HIP_NO_PROF_KEY, it is computed per register.  Same rows and coordinates as the oracle from both, on a batch
+    with many equal maxima (perfect repeats make the first-maximum rule matter)."""
+    import torch
+    n = 777
+    reads, refs = synth.make_pairs(n, R, F, seed=31, indel_rate=0.01, n_run_frac=0.03, short_frac=0.05)
+    refs[::3, F // 2:F // 2 + R] = reads[::3, :min(R, F - F // 2)][:, :R]            # a second copy of the read: tied maxima
+    osc = cpu_ref.Scoring.make(match, -1, -3, -3)
+    erows, eidx = cpu_ref.align(0, reads, refs, osc, threads=8)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    for computed in (False, True):
+        if computed:
+            monkeypatch.setenv("VALIGN_HIP_NO_PROF_KEY", "1")
+        eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(match, -1, -3, -3))
+        rows, idx = eng.align_device(0, d_reads, d_refs)
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), eidx) and np.array_equal(rows.cpu().numpy(), erows), (computed, prof_key)
+        eng.close()

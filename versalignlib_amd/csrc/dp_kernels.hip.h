@@ -223,7 +223,7 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
                                            int prof_area, int refc_stride, int wave_lds, short match,
                                            short mismatch, WaveTables &w, bool bad_is_non_acgt = false,
                                            unsigned block = blockIdx.x, short zero_score = 0,
-                                           int strip_row0 = kOneSweep) {
+                                           int strip_row0 = kOneSweep, short row_key_step = 0) {
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -316,15 +316,20 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
                 atomicMin(&first_bad[2 * p], pos);
             const bool valid = a >= 1 && a <= 4;
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
+            // row_key_step: every score of row q of a lane also carries (15 - q) * step -- the Smith-Waterman end-cell key
+            // of align_fill_tag_kernel<..., PROFKEY>, which then rides on every diagonal candidate for free
+            const short row_key = (short)(row_key_step * (15 - rr % K));
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const short sc = valid ? (a == c + 1 ? match : mismatch) : zero_score;
+                const short sc = (short)((valid ? (a == c + 1 ? match : mismatch) : zero_score) + row_key);
                 *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
             }
         }
-        const unsigned zero_pair = (unsigned)(unsigned short)zero_score * 0x00010001u;
-        for (int idx = lane; idx < geo::kPairStride / 4; idx += kWave)
-            reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = zero_pair;
+        for (int idx = lane; idx < geo::kPairStride / 4; idx += kWave) {          // dword idx: rows 2 idx, 2 idx + 1
+            const unsigned lo = (unsigned short)(zero_score + row_key_step * (15 - (2 * idx) % K));
+            const unsigned hi = (unsigned short)(zero_score + row_key_step * (15 - (2 * idx + 1) % K));
+            reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = lo | (hi << 16);
+        }
     }
     __syncthreads();
 #pragma unroll

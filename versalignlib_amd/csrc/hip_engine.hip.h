@@ -52,11 +52,12 @@ struct Geometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2][7];      // score kernels [alg][linear, symmetric linear, affine, symmetric affine,
                                    //                     symmetric affine / affine on half floats (SW only)]
-    const void *fill[2][11];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
+    const void *fill[2][12];        // alignment fill kernels [alg][linear, symmetric linear, affine, SSE policy,
                                    //                               linear with the pointer tagged into the cell, the same with
                                    //                               one end-cell key per lane (SW), symmetric affine,
                                    //                               affine / symmetric affine with tagged cells,
-                                   //                               SSE policy with tagged cells (per-row / lane key)]
+                                   //                               SSE policy with tagged cells (per-row / lane key),
+                                   //                               tagged with the end-cell key in the query profile (SW)]
 };
 
 template <int G, int K>
@@ -84,14 +85,15 @@ constexpr Geometry make_geometry() {
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, false>,
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgSW, true>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgSW, false, true>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true, true>},
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true, true>,
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgSW, true, false, false, true>},
                      {(const void *)&align_fill_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW, false>, (const void *)&align_fill_sse_kernel<G, K, kAlgNW>,
                       (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, false>, nullptr,
                       (const void *)&align_fill_affine_kernel<G, K, kAlgNW, true>,
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, false>,
                       (const void *)&align_fill_affine_tag_kernel<G, K, kAlgNW, true>,
-                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, true>, nullptr}}};
+                      (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, true>, nullptr, nullptr}}};
 }
 
 // Rows covered = G*K.  Ordered by capacity; selection is by estimated cost.
@@ -468,7 +470,8 @@ public:
         const bool affine_sym = sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
         const void *fn = sc_.affine ? kLongAffineKernels[alg][affine_sym ? 1 : 0][wide ? 1 : 0]
                                     : kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
-        const int long_lds = sc_.affine ? LongLds<kLongG, kLongK, true>::kTotal : LongLds<kLongG, kLongK, false>::kTotal;
+        int long_lds = sc_.affine ? LongLds<kLongG, kLongK, true>::kTotal : LongLds<kLongG, kLongK, false>::kTotal;
+        if (const char *pad = getenv("VALIGN_HIP_LONG_LDS")) long_lds = std::max(long_lds, atoi(pad));     // tuning switch: fewer waves per CU
         for (long long begin = 0; begin < n; begin += chunk) {
             const long long cnt = std::min(chunk, n - begin);
             a.reads = d_reads + (size_t)begin * R_;
@@ -753,8 +756,12 @@ public:
         // row for more than 16 rows per lane) still fits int16
         const long long key_top = ((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 1) << (plan_.geo->K <= 16 ? 4 : 5);
         const bool lane_key = tagged && alg == kAlgSW && key_top <= 32000;
+        // ... and where 64x the cell range fits (K <= 16), the key rides in the query profile instead of being computed
+        const bool prof_key = lane_key && !sse_policy_ && !no_prof_key_ && K <= 16 &&
+                              (((long long)std::min(R_, F_) * std::max(sc_.match, 0) + 2) << 6) <= 32000 &&
+                              64ll * std::max(std::abs(sc_.gap_read), std::abs(sc_.gap_ref)) < 32000 && 64ll * std::abs(sc_.mismatch) < 16000;
         const bool affine_sym = sc_.affine && sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
-        const void *fn = plan_.geo->fill[alg][tagged ? (sse_policy_ ? (lane_key ? 10 : 9) : (lane_key ? 5 : 4)) : (sse_policy_ ? 3 : (sc_.affine ? (affine_tagged ? (affine_sym ? 8 : 7) : (affine_sym ? 6 : 2)) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
+        const void *fn = plan_.geo->fill[alg][prof_key ? 11 : tagged ? (sse_policy_ ? (lane_key ? 10 : 9) : (lane_key ? 5 : 4)) : (sse_policy_ ? 3 : (sc_.affine ? (affine_tagged ? (affine_sym ? 8 : 7) : (affine_sym ? 6 : 2)) : ((sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0)))];
         const int block_lds = plan_.lds.total * plan_.waves_per_block;
         if (block_lds > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, block_lds),
@@ -1680,6 +1687,7 @@ private:
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     bool no_fused_ = getenv("VALIGN_HIP_NO_FUSED") != nullptr;   // tuning switch: small alignment calls as fill + traceback kernels
+    bool no_prof_key_ = getenv("VALIGN_HIP_NO_PROF_KEY") != nullptr;   // tuning switch: compute the SW lane key instead of carrying it in the profile
     bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch
     hipStream_t trace_stream_ = nullptr;                          // helper stream of align_device (walks beside the next fill)

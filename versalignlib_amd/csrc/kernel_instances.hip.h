@@ -53,6 +53,7 @@
     PREFIX __global__ void align_fill_affine_tag_kernel<G, K, kAlgNW, true>(const FillArgs);         \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, false, false>(const FillArgs);        \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, true, false>(const FillArgs);         \
+    PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, true, false, false, true>(const FillArgs); \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgNW, false, false>(const FillArgs);        \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, false, true>(const FillArgs);         \
     PREFIX __global__ void align_fill_tag_kernel<G, K, kAlgSW, true, true>(const FillArgs);          \

@@ -308,7 +308,7 @@ __device__ __forceinline__ void finish_block(unsigned *lane_base, long long bloc
 
 // End cell of each of the two pairs of a lane group, from the per-row first arg-max registers
 // (reference rules: DefaultKernel.cpp:252-256 for SW, :307-315 / :381-387 for the NW variant).
-template <int G, int K, int ALG, int KEYBITS = 0, int NT = 1>
+template <int G, int K, int ALG, int KEYBITS = 0, int NT = 1, int KEYLOW = 0>     // KEYLOW: bits below the row key (PROFKEY: the tag)
 __device__ __forceinline__ void write_end_cells(const FillArgs &args, const WaveTables &w, const s16x2 (&rb)[NT],
                                                 const s16x2 (&fc)[NT], const int (&ir)[2], const int (&jr)[2],
                                                 int pad_rows, int lane, int grp, int l, int score_shift = 0,
@@ -325,8 +325,8 @@ __device__ __forceinline__ void write_end_cells(const FillArgs &args, const Wave
             if constexpr (KEYBITS > 0) {
                 // one (value, row) key per lane: value << KEYBITS | (2^KEYBITS - 1 - row), and its first column
                 const int key = half ? rb[0].y : rb[0].x;
-                bv = key >> KEYBITS;
-                bq = ((1 << KEYBITS) - 1) - (key & ((1 << KEYBITS) - 1));
+                bv = key >> (KEYBITS + KEYLOW);
+                bq = ((1 << KEYBITS) - 1) - ((key >> KEYLOW) & ((1 << KEYBITS) - 1));
                 bcol = (half ? fc[0].y : fc[0].x) & 0xFFFF;
             } else {
 #pragma unroll
@@ -597,11 +597,17 @@ __host__ __device__ inline FusedLds<G, K> fused_lds(int wave_lds, int R, int F, 
     return f;
 }
 
-template <int G, int K, int ALG, bool LANEKEY, bool SSE, bool FUSED = false>
+// PROFKEY (Smith-Waterman, default tie-breaks, K <= 16): cells are 64 * H + 4 * key + tag, and the lane key of a cell --
+// value first, then 15 - row -- is not computed: the query profile carries 4 * (15 - row) in every score of the row, so the
+// diagonal candidate IS the key (a maximum of a Smith-Waterman matrix is always a diagonal arrival), and one packed
+// maximum per register tracks it.  One multiply-add per register less than LANEKEY; needs 64x headroom in int16.
+template <int G, int K, int ALG, bool LANEKEY, bool SSE, bool FUSED = false, bool PROFKEY = false>
 __global__ void __launch_bounds__(256)
 align_fill_tag_kernel(const FillArgs args) {
     static_assert(!LANEKEY || ALG == kAlgSW, "the lane key replaces the Smith-Waterman row arg-max");
     static_assert(!FUSED || (!LANEKEY && !SSE), "the fused kernel exists for the default tie-breaks");
+    static_assert(!PROFKEY || (LANEKEY && !SSE && !FUSED), "the profile key is a form of the lane key");
+    constexpr int kScale = PROFKEY ? 64 : 4;
     constexpr int kKeyBits = K <= 16 ? 4 : 5;
     using geo = Geo<G, K>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -620,9 +626,9 @@ align_fill_tag_kernel(const FillArgs args) {
     const int tilt_row = TILT ? -4 * args.gap_ref : 0, tilt_col = TILT ? -4 * args.gap_read : 0;
     const int tilt_diag = tilt_row + tilt_col;
     if (!wave_setup<G, K, true>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                args.wave_lds, (short)(4 * args.match + kDiagTag + tilt_diag),
-                                (short)(4 * args.mismatch + kDiagTag + tilt_diag), w, SSE,
-                                blockIdx.x, (short)((SSE ? 0 : 2) + tilt_diag)))
+                                args.wave_lds, (short)(kScale * args.match + kDiagTag + tilt_diag),
+                                (short)(kScale * args.mismatch + kDiagTag + tilt_diag), w, SSE,
+                                blockIdx.x, (short)((SSE ? 0 : 2) + tilt_diag), kOneSweep, (short)(PROFKEY ? 4 : 0)))
         return;
     const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
 
@@ -634,11 +640,12 @@ align_fill_tag_kernel(const FillArgs args) {
     // result carries tag 1); NW: signed addends 4g and 4g + 1
     // (SSE: signed addends in both modes, LEFT carries tag 2 and UP tag 1)
     constexpr bool kUnsignedGaps = ALG == kAlgSW && !SSE;
-    const s16x2 g_read = pk(kUnsignedGaps ? (short)(-4 * args.gap_read) : (short)(4 * args.gap_read + (SSE ? 2 : 0)));
-    const s16x2 g_ref = pk(kUnsignedGaps ? (short)(-4 * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
+    const s16x2 g_read = pk(kUnsignedGaps ? (short)(-kScale * args.gap_read) : (short)(4 * args.gap_read + (SSE ? 2 : 0)));
+    const s16x2 g_ref = pk(kUnsignedGaps ? (short)(-kScale * args.gap_ref - 1) : (short)(4 * args.gap_ref + 1));
     s16x2 four = pk(4), fifteen = pk(15), key_mul = pk((short)(1 << (kKeyBits - 2)));     // cells are 4 * H already
     unsigned tag_mask = 0x00030003u, clean4_mask = 0xFFFCFFFCu, up_mask = 0x00010001u;
-    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul), "+v"(clean4_mask), "+v"(up_mask));
+    unsigned clean_mask = PROFKEY ? 0xFFC0FFC0u : 0xFFFCFFFCu;          // everything below the value
+    asm volatile("" : "+v"(four), "+v"(fifteen), "+v"(tag_mask), "+v"(key_mul), "+v"(clean4_mask), "+v"(up_mask), "+v"(clean_mask));
 
     int ir[2], jr[2];
 #pragma unroll
@@ -742,9 +749,11 @@ align_fill_tag_kernel(const FillArgs args) {
             const s16x2 tt = pk((short)t);
             // pass1(q): diagonal and left candidates of row q and their maximum -- only the previous column
             // is needed, so it is computed one row ahead, between the links of the dependent chain
+            s16x2 step_key = pk(0);
             auto pass1 = [&](int q) __attribute__((always_inline)) -> s16x2 {
-                const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                               // tag 2
+                const s16x2 d = (q == 0 ? diag0 : Hl[q - 1]) + S[q];                               // tag 2 (PROFKEY: and the row key)
                 const s16x2 e = TILT ? Hl[q] : (kUnsignedGaps ? pk_sub_floor0(Hl[q], g_read) : Hl[q] + g_read);      // tag 0 (SSE: 2)
+                if (PROFKEY) step_key = pk_max(step_key, d);
                 return pk_max(d, e);
             };
             s16x2 h = up0;
@@ -752,9 +761,9 @@ align_fill_tag_kernel(const FillArgs args) {
             s16x2 hs = pk(0);
             s16x2 h_prev = pk(0);
             // arg-max bookkeeping of the previous row sits between the links of the dependent chain
-            s16x2 step_key = pk(0);
             auto finish_row = [&](int q, s16x2 hq) __attribute__((always_inline)) {
-                if (ALG == kAlgSW && LANEKEY) {
+                if (PROFKEY) {
+                } else if (ALG == kAlgSW && LANEKEY) {
                     step_key = pk_max(step_key, pk_mad_u(hq, key_mul, row_key[q]));
                 } else if (ALG == kAlgSW) {
                     const s16x2 changed = (rb[q] - hq) >> fifteen;   // 0xFFFF where h beats the row best
@@ -782,7 +791,7 @@ align_fill_tag_kernel(const FillArgs args) {
                 if (q > 0) finish_row(q - 1, h_prev);
                 tag[q] = as_pk(as_u32(ht) & tag_mask);
                 if (TILT) f_tilt = as_pk(__builtin_amdgcn_bitop3_b32(as_u32(ht), clean4_mask, up_mask, 0xEA));   // (ht & ~3) | 1
-                h = as_pk(as_u32(ht) & ~tag_mask);
+                h = as_pk(as_u32(ht) & clean_mask);
                 Hl[q] = h;
                 h_prev = h;
                 m_cur = m_next;
@@ -838,7 +847,9 @@ align_fill_tag_kernel(const FillArgs args) {
     if (last_only) sweep(std::true_type{});
     else sweep(std::false_type{});
 
-    if constexpr (LANEKEY) {
+    if constexpr (PROFKEY) {
+        write_end_cells<G, K, ALG, 4, 1, 2>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
+    } else if constexpr (LANEKEY) {
         write_end_cells<G, K, ALG, kKeyBits>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 0);
     } else if constexpr (!FUSED) {
         write_end_cells<G, K, ALG>(args, w, rb, fc, ir, jr, pad_rows, lane, grp, l, 2);
