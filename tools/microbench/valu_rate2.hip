@@ -21,7 +21,7 @@ enum Op {
     DOT2_I32_I16, SAD_U16, LSHL_ADD, BFE, MAX_U16,
     // second batch: the bit operations and 16-bit forms the tagged alignment kernels are made of, and a 1:1 mix
     AND_OR_B32, BFI_B32, LSHL_OR_B32, OR3_B32, XOR_B32, OR_B32, LSHLREV_B32, PK_ADD_I16, PK_ADD_I16_CLAMP,
-    PK_SUB_U16_CLAMP, PK_LSHLREV_B16, SUB_U32, MAX_I16, ADD_U16, BITOP3_B32, MIX_PKMAX_AND, MIX_PKMAX_AND_2TO1
+    PK_SUB_U16_CLAMP, PK_LSHLREV_B16, SUB_U32, MAX_I16, ADD_U16, BITOP3_B32, MIX_PKMAX_AND, MIX_PKMAX_AND_2TO1, ADD_U32_SDWA, ASHRREV_I32, BFE_I32
 };
 
 template <int OP>
@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(512) rate(unsigned *out, unsigned seed, long l
             if (OP == MAX_I16) asm volatile("v_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
             if (OP == ADD_U16) asm volatile("v_add_u16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
             if (OP == BITOP3_B32) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(g), "v"(h));
+            if (OP == ADD_U32_SDWA) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(r[i]) : "v"(g));
+            if (OP == ASHRREV_I32) asm volatile("v_ashrrev_i32 %0, 16, %0" : "+v"(r[i]));
+            if (OP == BFE_I32) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(r[i]));
             if (OP == MIX_PKMAX_AND) {          // half of the instructions packed maxima, half plain ANDs
                 if (i & 1) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(g));
                 else asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(g));
@@ -152,7 +155,7 @@ int main(int argc, char **argv) {
     if (argc > 1) {                                 // second batch only
         RUN(AND_OR_B32); RUN(BFI_B32); RUN(LSHL_OR_B32); RUN(OR3_B32); RUN(XOR_B32); RUN(OR_B32); RUN(LSHLREV_B32);
         RUN(PK_ADD_I16); RUN(PK_ADD_I16_CLAMP); RUN(PK_SUB_U16_CLAMP); RUN(PK_LSHLREV_B16); RUN(SUB_U32); RUN(MAX_I16);
-        RUN(ADD_U16); RUN(BITOP3_B32); RUN(MIX_PKMAX_AND); RUN(MIX_PKMAX_AND_2TO1);
+        RUN(ADD_U16); RUN(BITOP3_B32); RUN(MIX_PKMAX_AND); RUN(MIX_PKMAX_AND_2TO1); RUN(ADD_U32_SDWA); RUN(ASHRREV_I32); RUN(BFE_I32);
         return 0;
     }
     RUN(PK_MAX_I16); RUN(MAX_I32); RUN(ADD_U32); RUN(ADD_F32); RUN(FMA_F32); RUN(MAX_F32); RUN(MAX3_F32);
