@@ -318,3 +318,23 @@ def test_nw_frame_keeps_inside_its_cell_range(gap, cells):
         got = eng.score_device(host.NW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
         assert np.array_equal(got, cpu_ref.score(host.NW, reads, refs, cpu_ref.Scoring.make(2, -1, gap, gap), threads=8))
         eng.close()
+
+
+def test_nw_half_float_kernel_serves_two_different_gap_scores(monkeypatch):
+    """In the NW variant's tilted frame no gap constant is left in the recurrence (the row pays gap_ref, the column
+    gap_read, the diagonal both through the profile), so the 3-instruction half-float kernel also serves
+    gap_read != gap_ref; Smith-Waterman with two gap scores stays on int16.  Both forms equal the oracle."""
+    import torch
+    R, F, n = 150, 500, 2000
+    reads, refs = _data(R, F, n, 97)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    exp = cpu_ref.score(host.NW, reads, refs, cpu_ref.Scoring.make(2, -1, -2, -4), threads=8)
+    fast = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -2, -4))
+    assert fast.describe(host.NW)["score_cells"] == "f16" and fast.describe(host.SW)["score_cells"] == "int16"
+    assert np.array_equal(fast.score_device(host.NW, d_reads, d_refs).cpu().numpy(), exp)
+    fast.close()
+    monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+    plain = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -2, -4))
+    assert plain.describe(host.NW)["score_cells"] == "int16"
+    assert np.array_equal(plain.score_device(host.NW, d_reads, d_refs).cpu().numpy(), exp)
+    plain.close()

@@ -32,9 +32,13 @@
 //     tracking, affine 10, affine with the same open/extend for both directions 9.  Where every
 //     cell provably stays a small integer the same recurrences run on packed HALF FLOATS, which
 //     gfx950 gives a three-operand maximum (v_pk_maximum3_f16) and a free [0, 1] clamp on the
-//     add: shared-gap linear 4 (NW keeps H + g, SW keeps (h, max(h + g, 0)) scaled by 2^-10),
-//     symmetric affine 8, affine 9 -- results identical to the int16 forms, which remain the
-//     fallback.  The SW maximum is tracked on diag+S, off the dependency chain.
+//     add: shared-gap linear SW 4 (keeps (h, max(h + g, 0)) scaled by 2^-10), symmetric affine 8,
+//     affine 9 -- results identical to the int16 forms, which remain the fallback.  The SW maximum
+//     is tracked on diag+S, off the dependency chain.
+//   * The NW variant (no zero floor) runs every recurrence in a TILTED FRAME, cell (p, j) kept as
+//     V - g_ref * p - g_read * j: gap steps (affine: extensions) cost nothing, the diagonal pays for
+//     both through the query profile -- linear 3 packed instructions per register on half floats
+//     (perm, add, max3), 4 on int16; symmetric affine 6 / 7.  See score_kernel.
 //   * Pipeline fill/drain steps EXEC-mask lanes outside columns [0, F) (finished lanes keep
 //     the values of the last column, needed by the NW-variant result); the steady phase
 //     runs unmasked.
@@ -441,17 +445,15 @@ constexpr int kGapAffineSym = 3;   // affine with open_read == open_ref and ext_
 // integer of magnitude <= 2048, which fp16 represents exactly, and gfx950's v_pk_maximum3_f16
 // takes three operands -- h = max3(diag + S, E, F), E = max3(E - ext, H - open, 0) (which floors the
 // whole SW cell at zero) and the SW maximum tracking two rows at a time: 8.5 instead of 10 packed
-// instructions per register (NW variant: 8 instead of 9, gap matrices start at a real -inf).  The
+// instructions per register (NW variant, tilted frame: 6 instead of 7, gap matrices start at a real -inf).  The
 // engine picks it when shape x scoring stays inside +-2048.
 constexpr int kGapAffineSymF16 = 4;
 constexpr int kGapAffineF16 = 5;      // half floats with four different open / extend scores: 9.5 instead of 11
-// Linear gaps with gap_read == gap_ref for the NW variant on half floats, cells kept as H + g: "left + g"
-// and "up + g" are then simply the neighbours' registers, the diagonal term is (H + g)_diag + (S - g)
-// with S - g folded into the query profile, and h + g = max3(...) + g -- perm, add, max3, add: 4 packed
-// instructions per register instead of 5.  Smith-Waterman needs the zero floor as well: there every value
-// is additionally scaled by 2^-10 (exact for integers below 1024), which turns the floor into the
+// Linear gaps with gap_read == gap_ref on half floats.  NW variant: h = max3(diag + S', left, up) in the tilted
+// frame (score_kernel) -- perm, add, max3: 3 packed instructions per register.  Smith-Waterman needs the zero
+// floor: there every value is scaled by 2^-10 (exact for integers below 1024), which turns the floor into the
 // hardware clamp of v_pk_add_f16 -- max(h + g, 0) is ONE instruction, and a register pair (h, max(h + g, 0))
-// per cell gives h = max3(diag + S, left', up'), left' / up' being the clamped registers: also 4.
+// per cell gives h = max3(diag + S, left', up'), left' / up' being the clamped registers: 4 per register.
 constexpr int kGapSymF16 = 6;
 
 constexpr int kTrackAll = 0, kTrackNone = 1, kTrackPair = 2;   // see score_kernel's step

@@ -417,7 +417,9 @@ public:
             if (!no_f16_ && half_float_exact(alg, R, F, plan.geo->G * plan.geo->K)) gaps = gaps == kGapAffineSym ? kGapAffineSymF16 : kGapAffineF16;
         } else {
             gaps = (sc_.gap_read == sc_.gap_ref && !no_sym_) ? kGapSym : kGapLinear;
-            if (gaps == kGapSym && !no_f16_ && (alg == kAlgNW ? half_float_exact(alg, R, F, plan.geo->G * plan.geo->K) : half_float_unit_exact(R, F)))
+            // (the NW variant's tilted frame has no gap constants left: its half-float kernel serves gap_read != gap_ref too)
+            if ((gaps == kGapSym || alg == kAlgNW) && !no_f16_ &&
+                (alg == kAlgNW ? half_float_exact(alg, R, F, plan.geo->G * plan.geo->K) : half_float_unit_exact(R, F)))
                 gaps = kGapSymF16;
         }
         const void *fn = plan.geo->kernel[alg][gaps];
@@ -524,7 +526,7 @@ public:
         if (alg > 1) return "none";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
         if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K)) return "f16";
-        if (!plan_.long_mode && !sc_.affine && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ &&
+        if (!plan_.long_mode && !sc_.affine && ((sc_.gap_read == sc_.gap_ref && !no_sym_) || alg == kAlgNW) && !no_f16_ &&
             (alg == kAlgNW ? half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K) : half_float_unit_exact(R_, F_)))
             return "f16";
         return "int16";
