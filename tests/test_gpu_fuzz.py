@@ -1,8 +1,9 @@
 """Seeded differential sweep over shapes and scoring parameters: scores and alignments of
 libHIPKernel.so against the oracle, bit-exact, for combinations no hand-written case names (zero and
 equal gap scores, zero mismatch, large matches, tiny and lopsided shapes, every affine variant, both
-traceback policies).  Deterministic: the configurations come from splitmix64.  240 configurations by
-default; VALIGN_FUZZ_CASES=N runs the first N (round 1 was soaked with 4000: all bit-exact)."""
+traceback policies).  Deterministic: the configurations come from splitmix64.  700 configurations by
+default; VALIGN_FUZZ_CASES=N runs the first N (soaked with 4000 in both rounds; round 2's soak found case 604 --
+a half-float NW score above 2048 -- which is why the default run reaches past it)."""
 import numpy as np
 import pytest
 
@@ -53,7 +54,7 @@ def _scorings(c):
     return cpu_ref.Scoring.make(*args, **kw), hipkernel.Scoring.make(*args, **kw)
 
 
-@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("VALIGN_FUZZ_CASES", "240"))))
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("VALIGN_FUZZ_CASES", "700"))))
 def test_random_configuration(case):
     import torch
     c = _draw(case)

@@ -338,3 +338,23 @@ def test_nw_half_float_kernel_serves_two_different_gap_scores(monkeypatch):
     assert plain.describe(host.NW)["score_cells"] == "int16"
     assert np.array_equal(plain.score_device(host.NW, d_reads, d_refs).cpu().numpy(), exp)
     plain.close()
+
+
+@pytest.mark.parametrize("aff", [(0, 0, 0, 0), (-2, 0, -2, 0), None])
+def test_nw_half_float_results_beyond_2048(aff):
+    """Half-float NW cells live in a frame centred on zero, so a sweep whose best score is 170 x 13 = 2210 still runs
+    on halves when the gap (extension) scores tilt the frame little or not at all -- but the SCORE itself is then beyond
+    the exact range of a half: results are collected around half the best possible score and completed as integers
+    (a fuzz soak found 2067 returned as 2068).  Odd scores above 2048 must come back exact."""
+    import torch
+    R, F, n = 170, 222, 300
+    reads, refs = synth.make_pairs(n, R, F, seed=704, indel_rate=0.03, n_run_frac=0.05, short_frac=0.1)
+    kw = {} if aff is None else dict(open_read=aff[0], ext_read=aff[1], open_ref=aff[2], ext_ref=aff[3])
+    gap = 0 if aff is None else -7
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(13, 0, gap, gap, **kw))
+    assert eng.describe(host.NW)["score_cells"] == "f16"
+    got = eng.score_device(host.NW, torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+    exp = cpu_ref.score(host.NW, reads, refs, cpu_ref.Scoring.make(13, 0, gap, gap, **kw), threads=8, affine=aff is not None)
+    assert exp.max() > 2048 and (exp[exp > 2048] % 2 == 1).any()
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:8]
+    eng.close()

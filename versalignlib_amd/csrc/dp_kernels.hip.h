@@ -517,6 +517,10 @@ score_kernel(const ScoreArgs args) {
     // (borders start at -centre, results get it back) puts the sweep's value range [~0, top + tilt] around zero.  The
     // host checks the range with the same formula (Engine::half_float_exact).
     const int centre = (HALF && TILT) ? nw_frame_centre(args.R, F_batch, G * K, args.match, args.mismatch, tilt_row, tilt_col) : 0;
+    // ... and results are collected as "value - half the best possible score": what is taken off a cell on its way out
+    // of the frame, tilt - centre + rcentre, lies within +- half the frame's tilt and the difference within +- rcentre --
+    // every constant and every intermediate exact
+    const int rcentre = (HALF && TILT) ? nw_frame_centre(args.R, F_batch, G * K, args.match, args.mismatch, 0, 0) : 0;
     const float unit = LINF16_SW ? 1.0f / 1024.0f : 1.0f;
     auto cell = [](int v) __attribute__((always_inline)) {           // an integer in the cell format of this kernel, both halves
         return HALF ? pk(__builtin_bit_cast(short, (_Float16)v)) : pk((short)v);
@@ -574,7 +578,8 @@ score_kernel(const ScoreArgs args) {
         HOl[q] = (ALG == kAlgSW) ? pk(0) : (F16 ? cell_add(Hl[q], pk(__builtin_bit_cast(short, open_h))) : Hl[q] + o_ref);
     }
     s16x2 up0 = pk(0), h_last = Hl[K - 1], f_last = border_f, best = pk(0);
-    s16x2 row_best = pk(0);
+    // NW result: max(0, last row, last column) -- kept as "value - centre" (half floats: the sum itself may not be exact)
+    s16x2 row_best = cell(-rcentre);
     int j = -l;                                                  // this lane's column at step t
     // NW frame: the all-zero row above padded row 0, as the group leader sees it (row -1, column 1 at step 0, one
     // column on per step), and what the last padded row adds at this lane's column (taken off before the row maximum)
@@ -586,7 +591,7 @@ score_kernel(const ScoreArgs args) {
             top_step = col_step;                       // (stays zero in the other lanes: it is OR-ed into their row above)
             up0 = cell(-tilt_row - centre);            // row -1, column 0: the diagonal of the first cell
         }
-        row_tilt = cell(tilt_row * (G * K - 1) + tilt_col * (1 - l) - centre);
+        row_tilt = cell(tilt_row * (G * K - 1) + tilt_col * (1 - l) - centre + rcentre);
     }
 
     // LDS fetches run one step ahead of the arithmetic (every lane, every step: the code arrays are
@@ -850,21 +855,23 @@ score_kernel(const ScoreArgs args) {
         res = s16x2{(short)(int)((float)b.x * 1024.0f), (short)(int)((float)b.y * 1024.0f)};
     } else if (HALF) {
         f16x2 b = __builtin_bit_cast(f16x2, best);
-        if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column), out of the frame
-            b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : pk(0));
+        if (ALG == kAlgNW) {          // max(0, last column of every row, last row of every column), out of the tilt
+            b = __builtin_bit_cast(f16x2, l == G - 1 ? row_best : cell(-rcentre));
 #pragma unroll
             for (int q = 0; q < K; ++q)
-                b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, cell_sub(Hl[q], cell(tilt_row * (l * K + q) + tilt_col * F - centre))));
-            b = __builtin_elementwise_maximum(b, f16x2{(_Float16)0, (_Float16)0});
+                b = __builtin_elementwise_maximum(b, __builtin_bit_cast(f16x2, cell_sub(Hl[q], cell(tilt_row * (l * K + q) + tilt_col * F - centre + rcentre))));
+            // b >= -rcentre (the zero of the result rule); the rest of the score comes back as an integer
+            res = s16x2{(short)((int)b.x + rcentre), (short)((int)b.y + rcentre)};
+        } else {
+            res = s16x2{(short)(int)b.x, (short)(int)b.y};
         }
-        res = s16x2{(short)(int)b.x, (short)(int)b.y};
     } else if (ALG == kAlgSW) {
         res = best;
     } else {
         // last column: every lane froze at column F-1; last row: last register of lane G-1
         s16x2 col = l == G - 1 ? row_best : pk(0);
 #pragma unroll
-        for (int q = 0; q < K; ++q) col = pk_max(col, Hl[q] - cell(tilt_row * (l * K + q) + tilt_col * F - centre));
+        for (int q = 0; q < K; ++q) col = pk_max(col, Hl[q] - cell(tilt_row * (l * K + q) + tilt_col * F));
         res = pk_max(col, pk(0));
     }
 #pragma unroll
