@@ -159,8 +159,9 @@ constexpr FusedGeometry make_fused() {
                          {(const void *)&align_fill_tag_kernel<G, K, kAlgSW, false, false, true>,
                           (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, false, true>}};
 }
-static const FusedGeometry kFusedGeometries[] = {make_fused<8, 4>(), make_fused<16, 4>(), make_fused<16, 8>(),
-                                                 make_fused<16, 10>(), make_fused<32, 8>()};
+// (32 x 2 / 32 x 4: few rows per lane -- the shortest dependent chain per step, which is what a single-wave call costs)
+static const FusedGeometry kFusedGeometries[] = {make_fused<8, 4>(), make_fused<16, 4>(), make_fused<32, 2>(), make_fused<16, 8>(),
+                                                 make_fused<32, 4>(), make_fused<16, 10>(), make_fused<32, 8>()};
 
 struct LaunchPlan {
     bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
