@@ -315,6 +315,7 @@ public:
                 (void)hipEventDestroy(fill_done_[r]);
                 (void)hipEventDestroy(trace_done_[r]);
             }
+            (void)hipEventDestroy(entry_ev_);
             (void)hipStreamDestroy(trace_stream_);
         }
     }
@@ -749,7 +750,6 @@ public:
         chunk = std::max(ppb, chunk / ppb * ppb);
         chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
-        hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
         if (sse_policy_ && sc_.affine)
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
         // linear gaps, Default tie-breaks: the pointer rides in the low bits of the cell where 4x the cell
@@ -771,7 +771,8 @@ public:
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         // Parts of the batch: the traceback of one part runs on a helper stream beside the fill of the next (the walk
         // waits on memory at 17 % VALU issue, the fill owns the VALU).  A batch that fits the scratch in one piece is cut
-        // 7/8 + 1/8 -- the short fill covers the long walk, what stays exposed is the walk of the last eighth; a batch
+        // 7/8 + 1/8 -- the short fill covers the long walk, what stays exposed is the walk of the last eighth (cuts between
+        // 3/4 and 7/8 measure the same, finer ones lose to the second fill's own tail); a batch
         // that needs several chunks alternates between the two halves of the scratch.
         struct Part { long long begin, cnt, slot; int region; };
         std::vector<Part> parts;
@@ -788,7 +789,16 @@ public:
             for (long long begin = 0; begin < n; begin += chunk) parts.push_back(Part{begin, std::min(chunk, n - begin), 0, 0});
         }
         const bool helper = parts.size() > 1 && overlap;
-        if (helper) ensure_trace_stream();
+        if (helper) {
+            // the result rows are zeroed on the helper stream too (1.4 GB per million pairs of 150 x 500: the fills do not
+            // touch them), behind whatever the caller's stream was still doing with them
+            ensure_trace_stream();
+            hip_check(hipEventRecord(entry_ev_, stream), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(trace_stream_, entry_ev_, 0), "hipStreamWaitEvent");
+            hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, trace_stream_), "hipMemsetAsync(rows)");
+        } else {
+            hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
+        }
         bool region_used[2] = {false, false};
         for (const Part &part : parts) {
             const long long begin = part.begin, cnt = part.cnt;
@@ -870,6 +880,7 @@ public:
     void ensure_trace_stream() {
         if (trace_stream_) return;
         hip_check(hipStreamCreateWithFlags(&trace_stream_, hipStreamNonBlocking), "hipStreamCreate(traceback)");
+        hip_check(hipEventCreateWithFlags(&entry_ev_, hipEventDisableTiming), "hipEventCreate");
         for (int r = 0; r < 2; ++r) {
             hip_check(hipEventCreateWithFlags(&fill_done_[r], hipEventDisableTiming), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&trace_done_[r], hipEventDisableTiming), "hipEventCreate");
@@ -1694,7 +1705,7 @@ private:
     bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch
     hipStream_t trace_stream_ = nullptr;                          // helper stream of align_device (walks beside the next fill)
-    hipEvent_t fill_done_[2] = {nullptr, nullptr}, trace_done_[2] = {nullptr, nullptr};
+    hipEvent_t fill_done_[2] = {nullptr, nullptr}, trace_done_[2] = {nullptr, nullptr}, entry_ev_ = nullptr;
     std::string arch_;
     LaunchPlan plan_, latency_plan_;
     hipStream_t streams_[kSlots] = {};
