@@ -593,12 +593,14 @@ def main(argv=None):
                 rows = torch.empty((n, 2, AL), dtype=torch.uint8, device=device)
                 idx = torch.empty((n, 4), dtype=torch.int16, device=device)
                 line["alignments"] = {}
-                for name, e in (("nw_affine_traceback", eng), ("nw_linear_traceback", eng_lin)):
-                    e.align_device(1, reads, refs, rows, idx)
+                # (sw_linear: the call the reference's own timing loop makes, src/impl/main.cpp:278-287, device-resident here)
+                for name, e, opt in (("nw_affine_traceback", eng, 1), ("nw_linear_traceback", eng_lin, 1),
+                                     ("sw_linear_traceback", eng_lin, 0)):
+                    e.align_device(opt, reads, refs, rows, idx)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    e.align_device(1, reads, refs, rows, idx)
+                    e.align_device(opt, reads, refs, rows, idx)
                     e1.record()
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1)
