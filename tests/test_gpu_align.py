@@ -272,10 +272,13 @@ def test_largest_register_geometries(R, F, n):
     eng.close()
 
 
-def test_host_malloc_tuning_key_changes_nothing_but_the_allocator():
+@pytest.mark.parametrize("tuning", [0, 1, 2])
+def test_host_malloc_tuning_key_changes_nothing_but_the_allocator(tuning):
+    """host_malloc_tuning: 2 (default) grows glibc's arenas in 256 MB steps, 1 also stops trimming, 0 leaves the host's
+    allocator alone -- the rows handed out are the same operator new[] blocks with the same contents."""
     R, F, n = 64, 128, 5000
     reads, refs = _data(R, F, n, 93)
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, host_malloc_tuning=1) as hip:
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, host_malloc_tuning=tuning) as hip:
         for _ in range(2):                                    # second call recycles the first call's blocks
             got = hip.compute_alignments(host.SW, reads, refs, normalise=False)
         _assert_same(got, cpu_ref.align(host.SW, reads, refs, threads=8), "tuned")

@@ -94,14 +94,17 @@ public:
                 log_line(0, "hip_devices = " + std::to_string(shards) + ": shards on devices [" + where + "] of " +
                                 std::to_string(visible) + " visible");
             }
-            if (opt_param("host_malloc_tuning", 0) == 1) {
-                // compute_alignments must hand out 2n operator new[] blocks (the caller delete[]s them,
-                // include/AlignmentKernel.h:20-23).  At a million pairs glibc trims 1.4 GB back to the
-                // kernel on every free and faults it in again on the next call -- 175 ms instead of 50 on
-                // a 16-thread host.  Opt-in because it changes the allocator of the whole host process.
-                mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
-                mallopt(M_TOP_PAD, 256 << 20);
-            }
+            // compute_alignments must hand out 2n operator new[] blocks (the caller delete[]s them,
+            // include/AlignmentKernel.h:20-23) -- 1.4 GB per million pairs of 150 x 500, allocated by the scatter threads.
+            // glibc grows a thread arena in steps of M_TOP_PAD (128 KB by default), each one an mprotect() under the
+            // process's mm lock: with 16 threads that is what the call costs (650-850 ms per million pairs, the bare
+            // allocation loop without any plugin included -- tools/microbench/host_alloc.cpp).  256 MB steps make it
+            // 45-60 ms.  2 (default): M_TOP_PAD only -- address space is reserved in larger steps, pages are still
+            // committed on first touch and returned on free; 1: also never trim (the host keeps freed rows for the next
+            // call: the recycled case without relying on glibc's dynamic threshold); 0: leave the host's allocator alone.
+            const int tuning = opt_param("host_malloc_tuning", 2);
+            if (tuning == 1) mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
+            if (tuning == 1 || tuning == 2) mallopt(M_TOP_PAD, 256 << 20);
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
