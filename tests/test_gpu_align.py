@@ -420,7 +420,7 @@ def test_tracebacks_beside_the_next_fill(monkeypatch, cap_mb, overlap):
         monkeypatch.setenv("VALIGN_HIP_SCRATCH_CAP_MB", str(cap_mb))
     if not overlap:
         monkeypatch.setenv("VALIGN_HIP_NO_OVERLAP", "1")
-    R, F, blk, reps = 150, 500, 2048, 70          # 143 360 pairs = 1.08e10 cells: above the overlap threshold
+    R, F, blk, reps = 150, 500, 2039, 70          # 142 730 pairs (not a multiple of a block) = 1.07e10 cells: above the overlap threshold
     reads, refs = synth.make_pairs(blk, R, F, seed=77, indel_rate=0.01, junk_frac=0.02)
     eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3))
     d_reads = torch.from_numpy(reads).cuda().repeat(reps, 1).contiguous()
