@@ -10,6 +10,7 @@ for f in align_bench latency long_reads host_alloc; do cp $O/$f.txt profiles/${T
 [ -f $O/pmc_align_dispatches.txt ] && cp $O/pmc_align_dispatches.txt profiles/${TAG}_pmc_align_dispatches.txt
 cp "$(ls -t $O/prof_bench/runc/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_kernel_stats.csv
 cp "$(ls -t $O/prof_align/runc/*kernel_stats.csv | head -1)" profiles/${TAG}_align_kernel_stats.csv
+ls $O/prof_long/runc/*kernel_stats.csv > /dev/null 2>&1 && cp "$(ls -t $O/prof_long/runc/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_long_kernel_stats.csv
 python - <<PY
 import json, bench
 h = bench.source_hash()

@@ -18,6 +18,7 @@ echo "bench done"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-abi > $OUT/prof_bench.log 2>&1) || exit 1
 echo "bench trace done"
 python bench.py --workload long --steps 5 --warmup 1 > $OUT/bench_long.json 2> $OUT/bench_long.err || exit 1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_long -- python3 $R/bench.py --workload long --steps 3 --warmup 1 --no-cpu > $OUT/prof_long.log 2>&1) || exit 1
 echo "long bench done"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_align -- python3 $R/tools/align_bench.py --iters 2 > $OUT/prof_align.log 2>&1) || exit 1
 python tools/align_bench.py --iters 3 2>&1 | grep -v amdgpu.ids > $OUT/align_bench.txt || exit 1
