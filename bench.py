@@ -55,7 +55,8 @@ PAIRS_PER_GPU = 1 << 20
 LONG_R, LONG_F, LONG_PAIRS_PER_GPU, LONG_BAND = 10000, 10000, 32768, 512
 AFFINE = dict(open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
 HBM_PEAK_GBPS = 8000.0
-PMC_PROFILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_final.json")))
+PMC_PROFILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_final.json")) +
+                      glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_long_c5.json")))      # (--workload long's kernel)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -545,7 +546,7 @@ def main(argv=None):
         cells = d.get("score_cells", "int16")
         if long_mode:
             kernel_name = "score_long_kernel<16,10,SW,shared-gap,int32>"
-            pmc_key = "score_long_kernel<16, 10, 0, true, true>"
+            pmc_key = "score_long_kernel<16, 10, 0, true, true, false>"
             workload = ("%d pairs/GPU, 10 kbp x 10 kbp, SW linear-gap banded (%d diagonals), int32 cells, inputs resident in HBM%s"
                         % (n, LONG_BAND, ", RCCL all-gather of scores" if world > 1 else ""))
             metric = "GCUPS (giga DP cell updates/sec, full-matrix cells) SW banded, 10 kbp x 10 kbp"

@@ -17,6 +17,10 @@ python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err || exit 1
 echo "bench done"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-abi > $OUT/prof_bench.log 2>&1) || exit 1
 echo "bench trace done"
+# the long workload's kernel (BASELINE configs[4] per GPU: 32768 pairs of 10 kbp x 10 kbp, band 512, int32 cells): PMC first, so that its bench line can quote it
+bash tools/pmc_long.sh c5 --R 10000 --F 10000 --n 32768 --band 512 --width 32 > $OUT/pmc_long_c5.log 2>&1
+python tools/pmc_summary.py $R/gpurun_out/pmc_c5 32768 > $OUT/pmc_long_c5.json || exit 1
+cp $OUT/pmc_long_c5.json $R/profiles/${TAG}_pmc_long_c5.json
 python bench.py --workload long --steps 5 --warmup 1 > $OUT/bench_long.json 2> $OUT/bench_long.err || exit 1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_long -- python3 $R/bench.py --workload long --steps 3 --warmup 1 --no-cpu > $OUT/prof_long.log 2>&1) || exit 1
 echo "long bench done"
