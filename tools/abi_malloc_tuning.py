@@ -1,6 +1,14 @@
-import sys, json, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import torch, bench
+"""compute_alignments(SW) through the plugin ABI with rows of earlier calls alive (the reference's leaking timing loop),
+1M pairs of 150 x 500, for one value of the plugin key host_malloc_tuning (argv[1]: 0, 1, 2) -- and the bare 2n new[]
+loop before and after the spawn (developer tool; run on the GPU box, one process per value: mallopt is sticky)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
 from versalignlib_amd import build, host
 n = 1 << 20
 reads, refs = bench.synth_on_device(n, torch.device("cuda:0"), seed=2000)

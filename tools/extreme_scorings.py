@@ -1,5 +1,12 @@
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+"""Large gap / match scores through every cell format the engine can pick (half floats, int16, int32 strips, equality-test
+fallbacks), scores and alignments against the oracle (developer tool; run on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cpu_ref
 from versalignlib_amd import hipkernel, synth
 R, F, n = 150, 500, 300
