@@ -15,7 +15,7 @@ reads, refs = bench.synth_on_device(n, torch.device("cuda:0"), seed=2000)
 h_reads, h_refs = reads.cpu().numpy(), refs.cpu().numpy()
 tune = int(sys.argv[1])
 keys = dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5, score_gap_extend_ref=-1)
-if tune: keys["host_malloc_tuning"] = tune
+keys["host_malloc_tuning"] = tune
 floor0, _ = host.alloc_probe(n, 650, 16)
 with host.Plugin(build.HIP_PLUGIN, 150, 500, num_threads=16, **keys) as k:
     floor1, _ = host.alloc_probe(n, 650, 16)
