@@ -104,7 +104,12 @@ public:
             // call: the recycled case without relying on glibc's dynamic threshold); 0: leave the host's allocator alone.
             const int tuning = opt_param("host_malloc_tuning", 2);
             if (tuning == 1) mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
-            if (tuning == 1 || tuning == 2) mallopt(M_TOP_PAD, 256 << 20);
+            if (tuning == 1 || tuning == 2) {
+                mallopt(M_TOP_PAD, 256 << 20);
+                log_line(0, std::string("host_malloc_tuning = ") + std::to_string(tuning) +
+                                ": mallopt(M_TOP_PAD, 256 MB)" + (tuning == 1 ? " + M_TRIM_THRESHOLD off" : "") +
+                                " for the result rows of compute_alignments (0 leaves the host's allocator alone)");
+            }
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
             log_line(3, what_);
