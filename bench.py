@@ -351,12 +351,14 @@ def abi_leg(reads, refs, threads, devices=1):
     # compute_alignments(SW) hands out 2n operator new[] rows per call (include/AlignmentKernel.h:20-23).  What that costs
     # is glibc's arena growth: 128 KB steps (an mprotect each, 16 threads contending) by default, 256 MB steps with the
     # plugin's default host_malloc_tuning = 2 (mallopt(M_TOP_PAD), process-wide and sticky: the untuned figures first).
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=0, **keys) as k:
-        floor_untuned, _ = host.alloc_probe(n, R + F, threads)
-        k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
-        _, per_call = k.time_calls(0, h_reads, h_refs, reps=2, align=True, free_between=False)
-        untuned = {"ms_fresh_rows": round(min(per_call) * 1e3, 2), "ms_2n_fresh_new_rows_alone": round(floor_untuned * 1e3, 2),
-                   "note": "host_malloc_tuning = 0: glibc's default 128 KB arena steps"}
+    untuned = None
+    if devices <= 1:            # (the first abi_leg of the process: no plugin object has changed the allocator yet)
+        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=0, **keys) as k:
+            floor_untuned, _ = host.alloc_probe(n, R + F, threads)
+            k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
+            _, per_call = k.time_calls(0, h_reads, h_refs, reps=2, align=True, free_between=False)
+            untuned = {"ms_fresh_rows": round(min(per_call) * 1e3, 2), "ms_2n_fresh_new_rows_alone": round(floor_untuned * 1e3, 2),
+                       "note": "host_malloc_tuning = 0: glibc's default 128 KB arena steps"}
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
         k.score_alignments(0, h_reads[:65536], h_refs[:65536], scattered=True)
         k.score_alignments(0, h_reads, h_refs, scattered=True)
