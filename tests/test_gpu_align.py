@@ -459,3 +459,22 @@ def test_sw_end_cell_key_in_the_profile_or_computed(monkeypatch, R, F, match, pr
         torch.cuda.synchronize()
         assert np.array_equal(idx.cpu().numpy(), eidx) and np.array_equal(rows.cpu().numpy(), erows), (computed, prof_key)
         eng.close()
+
+
+@pytest.mark.gpu
+def test_host_pointer_alignments_of_a_large_batch():
+    """compute_alignments' host-pointer pipeline with chunks large enough for the helper-stream schedule (a chunk of
+    256 MB of result rows is 1.15e10 cells at 150 x 500): rows and coordinates repeat with the period of the repeated
+    block and equal the oracle on it, in both modes."""
+    R, F, blk, reps = 150, 500, 1999, 100                     # 199 900 pairs: one full chunk and a short one
+    reads, refs = synth.make_pairs(blk, R, F, seed=79, indel_rate=0.01, junk_frac=0.02)
+    big_reads, big_refs = np.tile(reads, (reps, 1)), np.tile(refs, (reps, 1))
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3))
+    for opt in (0, 1):
+        rows, idx = eng.align_host(opt, big_reads, big_refs, threads=8)
+        rows = rows.reshape(reps, blk, 2, R + F)
+        idx = idx.reshape(reps, blk, 4)
+        assert (rows == rows[0:1]).all() and (idx == idx[0:1]).all()
+        erows, eidx = cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3), threads=8)
+        assert np.array_equal(idx[0], eidx) and np.array_equal(rows[0], erows)
+    eng.close()
