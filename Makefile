@@ -13,6 +13,11 @@ test:
 test-gpu:
 	$(PY) -m pytest tests -q -m gpu
 
+# CPU sanitizers: host_pipeline.h under TSan and ASan/UBSan, then the CPU suite against -fsanitize builds of
+# libvalignhost.so, valign-bench and oracle/cpu_ref.c (tools/sanitize.sh)
+sanitize:
+	tools/sanitize.sh
+
 smoke:
 	$(PY) -c "import __graft_entry__ as g; g.smoke()"
 
@@ -22,4 +27,4 @@ bench:
 clean:
 	rm -rf versalignlib_amd/build versalignlib_amd/lib oracle/libcpuref.so oracle/_ref
 
-.PHONY: all build test test-gpu smoke bench clean
+.PHONY: all build test test-gpu sanitize smoke bench clean

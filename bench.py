@@ -32,6 +32,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                    host pointers): score_alignments and compute_alignments(SW) on the full batch,
                    and the reference host's own protocol (100 back-to-back calls, src/impl/main.cpp
                    :268-292) on BASELINE configs[0].  Never part of `value`.
+  verified ....... the scores the LAST TIMED STEP wrote, compared with the oracle inside this run (the sample
+                   cpu_baseline scored: hundreds of thousands of pairs at N = 1); a mismatch exits non-zero.
+                   The alignment legs carry their own `verified` (first 2048 pairs, rows + coordinates).
   linear_gap ..... the same batch in the reference's own linear-gap model (the bit-exact
                    path), and the reference's compiled CPU kernels timed beside it when
                    oracle/_ref travelled with the repo.
@@ -104,7 +107,7 @@ def launch_ranks(args, argv):
 def source_hash():
     """sha256 over the kernel sources: PMC profiles are only quoted for the sources they were taken from."""
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "versalignlib_amd", "csrc", "*"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "versalignlib_amd", "csrc", "*.hip*"))):      # (not the host-only .cpp files)
         if os.path.isfile(path):
             h.update(os.path.basename(path).encode())
             h.update(open(path, "rb").read())
@@ -154,6 +157,18 @@ def measured_valu_issue(kernel_key, pairs):
         return {"bound": "valu-issue", "wave_instructions": float(k["SQ_INSTS_VALU"]),
                 "issue_cycles_per_simd": round(issue), "kernel_cycles": round(cycles),
                 "frac": round(issue / cycles, 4), "source": "committed profile " + path}
+    except (KeyError, ValueError, TypeError, ZeroDivisionError):
+        return None
+
+
+def measured_lds_conflicts(kernel_key, pairs):
+    """LDS bank-conflict cycles as a share of the cycles the LDS was busy (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE,
+    the north star's second counter), from the same committed profile."""
+    k, _ = pmc_profile(kernel_key, pairs)
+    if k is None:
+        return None
+    try:
+        return round(float(k["SQ_LDS_BANK_CONFLICT"]) / float(k["SQ_LDS_IDX_ACTIVE"]), 4)
     except (KeyError, ValueError, TypeError, ZeroDivisionError):
         return None
 
@@ -224,20 +239,49 @@ def kernel_launch_ms(eng, opt, reads, refs, out, reps):
     return sum(a.elapsed_time(b) for a, b in ev) / reps
 
 
-def host_cores():
-    cores = os.cpu_count() or 1
+def host_cpus():
+    """What this process may really use: the CPUs of its affinity mask, capped by the cgroup's CFS quota
+    (a container on a 256-thread host with `cpu.max = 1600000 100000` gets 16 CPUs' worth of time however many
+    threads it starts -- more threads than that are throttled, not faster)."""
+    logical = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
-    return cores
+        affinity = logical
+    quota, quota_text = None, "none"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2
+            q, period = f.read().split()[:2]
+        quota_text = "%s %s" % (q, period)
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                                            # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            quota_text = "%d %d" % (q, period)
+            if q > 0:
+                quota = q / float(period)
+        except (OSError, ValueError):
+            pass
+    effective = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"effective": effective, "logical_cpus": logical, "affinity": affinity, "cpu_quota": quota_text}
+
+
+def host_cores():
+    return host_cpus()["effective"]
 
 
 def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
-    """Oracle on the host cores over a bounded sample of the same batch (rank 0, N == 1)."""
+    """Oracle on the host cores over a bounded sample of the same batch (rank 0, N == 1): threads = the CPUs this
+    process really has (host_cpus).  Returns (record, oracle scores of the sample) -- the scores are what the timed
+    kernel's output is verified against."""
     from oracle import cpu_ref
     cpu_ref.build()
-    cores = min(cpu_ref.max_threads(), host_cores())
+    cpus = host_cpus()
+    cores = max(1, min(cpu_ref.max_threads(), cpus["effective"]))
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, **(AFFINE if affine else {}))
 
     def run(h_reads, h_refs):
@@ -254,13 +298,51 @@ def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
     sample = int(min(reads.shape[0], max(probe, rate * seconds)))
     h_reads, h_refs = reads[:sample].cpu().numpy(), refs[:sample].cpu().numpy()
     t0 = time.perf_counter()
-    run(h_reads, h_refs)
+    scores = run(h_reads, h_refs)
     sec = time.perf_counter() - t0
     what = "SW %s int16" % ("affine-gap" if affine else "linear-gap") if not band else "SW linear-gap banded (%d diagonals)" % band
     cells = float(sample) * R * F
-    return {"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
-            "sample": "first %d pairs of the rank-0 batch, %s, oracle/cpu_ref.c OpenMP over pairs, %.1f s%s"
-                      % (sample, what, sec, " (full-matrix cells counted, as for the GPU)" if band else "")}
+    return {"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "logical_cpus": cpus["logical_cpus"],
+            "affinity_cpus": cpus["affinity"], "cpu_quota": cpus["cpu_quota"], "kind": "port",
+            "sample": "first %d pairs of the rank-0 batch, %s, oracle/cpu_ref.c OpenMP over pairs on %d threads (= the CPUs "
+                      "the cgroup quota and the affinity mask give this process), %.1f s%s"
+                      % (sample, what, cores, sec, " (full-matrix cells counted, as for the GPU)" if band else "")}, scores
+
+
+def verify_scores(device_scores, reads, refs, affine, R=R, F=F, band=0, oracle_scores=None, pairs=8192):
+    """The scores of the timed kernel against the oracle, inside the driver's own run: `oracle_scores` (what
+    cpu_baseline computed for the first len(oracle_scores) pairs) or a fresh oracle run over the first `pairs`."""
+    import numpy as np
+    from oracle import cpu_ref
+    if oracle_scores is None:
+        cpu_ref.build()
+        m = int(min(pairs, reads.shape[0]))
+        sc = cpu_ref.Scoring.make(2, -1, -3, -3, **(AFFINE if affine else {}))
+        h_reads, h_refs = reads[:m].cpu().numpy(), refs[:m].cpu().numpy()
+        th = max(1, min(cpu_ref.max_threads(), host_cores()))
+        if band:
+            oracle_scores = cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=th, block_rows=160, col_align=4)
+        else:
+            oracle_scores = cpu_ref.score(0, h_reads, h_refs, sc, threads=th, affine=affine)
+    m = len(oracle_scores)
+    got = device_scores[:m].cpu().numpy()
+    bad = int(np.count_nonzero(got != np.asarray(oracle_scores, dtype=np.int16)))
+    return {"pairs": m, "mismatches": bad, "against": "oracle/cpu_ref.c (restatement of DefaultKernel.cpp:83-202%s), "
+            "first %d pairs of the timed batch, scores of the timed kernel" % (" + affine extension" if affine else "", m)}
+
+
+def verify_alignments(rows, idx, opt, reads, refs, affine, pairs=2048):
+    """Rows and coordinates of a device alignment leg against the oracle on the first `pairs` pairs."""
+    import numpy as np
+    from oracle import cpu_ref
+    cpu_ref.build()
+    m = int(min(pairs, reads.shape[0]))
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, **(AFFINE if affine else {}))
+    th = max(1, min(cpu_ref.max_threads(), host_cores()))
+    exp_rows, exp_idx = cpu_ref.align(opt, reads[:m].cpu().numpy(), refs[:m].cpu().numpy(), sc, threads=th, affine=affine)
+    got_rows, got_idx = rows[:m].cpu().numpy(), idx[:m].cpu().numpy()
+    bad = int(np.count_nonzero((got_rows.reshape(m, -1) != exp_rows.reshape(m, -1)).any(axis=1) | (got_idx != exp_idx).any(axis=1)))
+    return {"pairs": m, "mismatches": bad}
 
 
 def reference_cpu_kernels(reads, refs):
@@ -523,6 +605,7 @@ def main(argv=None):
     elapsed = timed_steps(step, args.steps, args.warmup, world)
     total_cells = float(n) * RR * FF * world * args.steps
     value = total_cells / elapsed / 1e9
+    timed_scores = local.clone() if rank == 0 else None       # what the last timed step wrote (later legs reuse `local`)
 
     multi = None
     if world > 1:
@@ -573,7 +656,8 @@ def main(argv=None):
                          "note": "integer VALU bound: %.5f B/cell algorithmic, HBM is idle by design; traffic / valu are quoted "
                                  "from a committed PMC profile only when it was taken from these exact kernel sources (csrc %s)"
                                  % ((RR + FF + 2) / (RR * FF), source_hash()),
-                         "valu": measured_valu_issue(pmc_key, n)},
+                         "valu": measured_valu_issue(pmc_key, n),
+                         "lds_bank_conflict_frac": measured_lds_conflicts(pmc_key, n)},
         }
         if multi is not None:
             line["multi_gpu"] = multi
@@ -607,8 +691,8 @@ def main(argv=None):
                 idx = torch.empty((n, 4), dtype=torch.int16, device=device)
                 line["alignments"] = {}
                 # (sw_linear: the call the reference's own timing loop makes, src/impl/main.cpp:278-287, device-resident here)
-                for name, e, opt in (("nw_affine_traceback", eng, 1), ("nw_linear_traceback", eng_lin, 1),
-                                     ("sw_linear_traceback", eng_lin, 0)):
+                for name, e, opt, aff in (("nw_affine_traceback", eng, 1, True), ("nw_linear_traceback", eng_lin, 1, False),
+                                          ("sw_linear_traceback", eng_lin, 0, False)):
                     e.align_device(opt, reads, refs, rows, idx)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -618,7 +702,10 @@ def main(argv=None):
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1)
                     line["alignments"][name] = {"ms": round(ms, 3), "gcups": round(n * RR * FF / (ms * 1e-3) / 1e9, 1),
-                                                "algorithmic_GBps": round(n * (3 * AL + 8) / (ms * 1e-3) / 1e9, 1)}
+                                                "algorithmic_GBps": round(n * (3 * AL + 8) / (ms * 1e-3) / 1e9, 1),
+                                                "verified": verify_alignments(rows, idx, opt, reads, refs, aff)}
+                    if line["alignments"][name]["verified"]["mismatches"]:
+                        rc = 4
                 del rows, idx
             except hipkernel.HipKernelError as e:
                 line["alignments"] = {"error": str(e)[:200]}
@@ -634,14 +721,24 @@ def main(argv=None):
                         line["abi_in_plugin_shards"] = abi_leg(reads, refs, threads, devices=min(world, visible))
                 except Exception as e:
                     line["abi"] = {"error": str(e)[:300]}
+        oracle_scores = None
         if world == 1 and not args.no_cpu:
             if long_mode:
-                line["cpu_baseline"] = cpu_baseline(reads, refs, affine=False, R=RR, F=FF, band=LONG_BAND)
+                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=False, R=RR, F=FF, band=LONG_BAND)
             else:
-                line["cpu_baseline"] = cpu_baseline(reads, refs, affine=True)
-                line["linear_gap"]["cpu_port"] = cpu_baseline(reads, refs, affine=False)
+                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=True)
+                line["linear_gap"]["cpu_port"], _ = cpu_baseline(reads, refs, affine=False)
                 line["linear_gap"]["cpu_reference"] = reference_cpu_kernels(reads, refs)
+        # the timed kernel's own output against the oracle, in this very run: the sample cpu_baseline scored (or a
+        # small fresh one when the CPU legs are off / N > 1); a mismatch fails the run
+        line["verified"] = verify_scores(timed_scores, reads, refs, affine=not long_mode, R=RR, F=FF,
+                                         band=LONG_BAND if long_mode else 0, oracle_scores=oracle_scores,
+                                         pairs=8192 if not long_mode else 16)
+        if line["verified"]["mismatches"]:
+            rc = 4
         print(json.dumps(line), flush=True)
+        if rc == 4:
+            print("bench.py: results differ from the oracle (see `verified`)", file=sys.stderr)
     if world > 1:
         dist.barrier(group=gloo)
         dist.destroy_process_group()

@@ -25,17 +25,24 @@
  *                                                         int32 where int16 could overflow), 16, 32
  *       ragged_batching ................................. length-sorted Smith-Waterman score calls
  *                                                         (trailing non-ACGT padding is not swept,
- *                                                         identical scores): 0 never, 1 when a sample
- *                                                         of the call is ragged enough (default), 2 always
- *       host_malloc_tuning .............................. 1: mallopt(M_TRIM_THRESHOLD / M_TOP_PAD) at spawn so that
- *                                                         the 2n result blocks of large compute_alignments
- *                                                         calls are recycled instead of trimmed and re-faulted
- *                                                         (changes the host's allocator; default 0)
+ *                                                         identical scores): 0 never (default), 1 when a
+ *                                                         sample of the call is ragged enough, 2 always
+ *       host_malloc_tuning .............................. what spawning a kernel does to the HOST's allocator
+ *                                                         (process-wide!): 2 (default) mallopt(M_TOP_PAD, 256 MB)
+ *                                                         -- arenas grow in 256 MB steps, which takes the 2n
+ *                                                         operator new[] result rows of a million-pair
+ *                                                         compute_alignments call from ~700 ms to ~50 ms;
+ *                                                         1 also M_TRIM_THRESHOLD off; 0 touches nothing.
+ *                                                         Logged at WARNING level the first time
+ *       pointer_scratch_cap_mb .......................... cap of compute_alignments' device-side pointer
+ *                                                         scratch in MiB (default 0: 64 GiB / half the free HBM)
  *       hip_device ...................................... device ordinal (default 0)
  *       hip_devices ..................................... N > 1: every call is split into N contiguous shards of
  *                                                         pairs, one per device (hip_device .. hip_device+N-1,
- *                                                         modulo the visible ones), each on its own host thread;
+ *                                                         modulo the visible ones -- folding is announced at
+ *                                                         WARNING level), each on its own host thread;
  *                                                         results land in the caller's arrays (default 1)
+ *       hip_devices_strict .............................. 1: refuse hip_devices beyond the visible devices
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
  * (2) A flat C view of the same engine for callers that already hold the batch in
@@ -106,6 +113,12 @@ int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
 #define VALIGN_HIP_BAND_BLOCK_ROWS 160
 #define VALIGN_HIP_BAND_COL_ALIGN 4
 int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
+
+/* Cap (MiB) of the internal pointer scratch compute_alignments keeps in device memory (2 bits per cell and pair,
+ * 4 with affine gaps: 20.8 / 41.6 KB per pair at 150 x 500).  0 (default): up to 64 GiB or half the free HBM,
+ * whichever is smaller; batches that need more than the cap run in chunks -- same results, more launches.
+ * Plugin key: pointer_scratch_cap_mb.                                                                       */
+int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb);
 
 /* DP cell width of the score path: 0 (default) = int16 like the reference, switching to int32 cells
  * for (shape, scoring, mode) whose cells could leave int16 (the reference would wrap silently);

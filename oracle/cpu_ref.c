@@ -26,8 +26,14 @@
  *     char there, which is undefined).
  *
  * The affine-gap (Gotoh) functions at the bottom are an EXTENSION with no
- * reference counterpart ("parity unpinned by the reference"); they are pinned
- * only by the identity affine(open == extend == g) == linear(g).
+ * reference counterpart ("parity unpinned by the reference").  They are pinned
+ * independently of this file: (i) affine(open == extend == g) == the reference-pinned
+ * linear(g) bit for bit; (ii) exhaustive enumeration of every alignment of tiny pairs
+ * (tests/enumerate_alignments.py -> the .npz files of tests/golden/affine, no dynamic program);
+ * (iii) the general-gap-function recurrence without E/F state at sizes enumeration
+ * cannot reach (tests/test_affine_enumeration.py).  The banded and int32 entry points
+ * are pinned by band >= matrix == unbanded == reference, the per-cell / block sandwich,
+ * and int32 == int16 wherever int16 does not overflow.
  *
  * Data layout for every entry point: reads = n*R bytes, pair-major contiguous;
  * refs = n*F bytes likewise; each sequence exactly R / F bytes, short ones

@@ -12,6 +12,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libcpuref.so")
+_SANITIZED = os.environ.get("VALIGN_SANITIZED_DIR") or None      # tools/sanitize.sh: the -fsanitize build of this file
+if _SANITIZED:
+    _LIB_PATH = os.path.join(_SANITIZED, "libcpuref.so")
 REF_DIR = os.path.join(_HERE, "_ref")
 
 
@@ -34,6 +37,8 @@ class Scoring(ctypes.Structure):
 
 def build(force=False):
     """Compile libcpuref.so (and oracle/_ref when the reference tree is present)."""
+    if _SANITIZED:
+        return
     src = os.path.join(_HERE, "cpu_ref.c")
     stale = (not os.path.exists(_LIB_PATH)
              or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))

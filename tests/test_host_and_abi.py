@@ -79,6 +79,16 @@ def test_fasta_and_pad(tmp_path):
     padded = host.pad(seqs)
     assert padded.shape == (3, 10)
     assert bytes(padded[0]) == b"ACGTAC\0\0\0\0" and bytes(padded[2]) == b"AC" + b"\0" * 8
+    # the corners of the reference parser's acceptance rules (src/util/versalignUtil.h:60-92): a record without sequence
+    # lines is an empty sequence; a bare '>' names nothing and its lines are skipped; lines before the first header are
+    # skipped; a voided record stays voided until the next header; a last line without newline is not read; a
+    # sequence ends at an embedded NUL; carriage returns are ordinary bytes
+    fb = tmp_path / "y.fa"
+    fb.write_bytes(b"stray\n>e\n>\nAAAA\n>f\nAC GT\nTTTT\n\nGG\n>g\nAC\0GT\nTT\n>h\nAC\r\n>i\nGGG\nTT")
+    assert host.parse_fasta(str(fb)) == [b"", b"AC", b"AC\r", b"GGG"]
+    fc = tmp_path / "z.fa"
+    fc.write_bytes(b"")
+    assert host.parse_fasta(str(fc)) == []
 
 
 def test_synth_is_deterministic_and_shaped():

@@ -19,12 +19,18 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_PLUGIN = os.path.join(LIB, "libHIPKernel.so")
 HOST_LIB = os.path.join(LIB, "libvalignhost.so")
 BENCH_CLI = os.path.join(LIB, "valign-bench")
+# `make sanitize` (tools/sanitize.sh) builds the host-side pieces with -fsanitize=address,undefined into a directory
+# of its own and points the test-suite at them; nothing is rebuilt from here then
+SANITIZED_DIR = os.environ.get("VALIGN_SANITIZED_DIR") or None
+if SANITIZED_DIR:
+    HOST_LIB = os.path.join(SANITIZED_DIR, "libvalignhost.so")
+    BENCH_CLI = os.path.join(SANITIZED_DIR, "valign-bench")
 
 HIP_SOURCES = ["hip_plugin.hip"]
 HIP_KERNEL_PART = "kernel_part.hip"          # compiled once per part (kernel_instances.hip.h), in parallel
 HIP_KERNEL_PARTS = 7
 HIP_DEPS = ["hip_plugin.hip", "kernel_part.hip", "kernel_instances.hip.h", "dp_kernels.hip.h", "trace_kernels.hip.h",
-            "long_kernels.hip.h", "strip_kernels.hip.h", "hip_engine.hip.h"]
+            "long_kernels.hip.h", "strip_kernels.hip.h", "hip_engine.hip.h", "host_pipeline.h"]
 OBJ = os.path.join(PKG, "build")             # intermediate objects (git-ignored)
 HOST_SOURCES = ["valign_host.cpp"]
 
@@ -51,6 +57,10 @@ def hipcc_path():
 
 
 def build_host(force=False):
+    if SANITIZED_DIR:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("VALIGN_SANITIZED_DIR is set but %s is missing: run tools/sanitize.sh" % HOST_LIB)
+        return HOST_LIB
     os.makedirs(LIB, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     deps = srcs + [os.path.join(INCLUDE, h) for h in ("valign_host.h", "versalign_plugin_abi.h")]

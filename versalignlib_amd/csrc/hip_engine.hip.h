@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_pipeline.h"
 #include "kernel_instances.hip.h"
 #include "long_kernels.hip.h"
 #include "strip_kernels.hip.h"
@@ -171,88 +172,6 @@ struct LaunchPlan {
     int pairs_per_wave = 0;
 };
 
-// Host worker threads that outlive a call: gather / scatter run on them chunk after chunk (spawning
-// num_threads std::threads per chunk cost as much as the copying itself).  run(parts, fn) calls
-// fn(part) for every part in [0, parts) on the workers and the calling thread and returns when all
-// are done; an exception from fn is rethrown on the caller.
-class WorkerPool {
-public:
-    explicit WorkerPool(int workers) {
-        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            stop_ = true;
-        }
-        wake_.notify_all();
-        for (auto &t : threads_) t.join();
-    }
-    int workers() const { return (int)threads_.size(); }
-
-    void run(int parts, const std::function<void(int)> &fn) {
-        if (parts <= 0) return;
-        if (parts == 1 || threads_.empty()) {
-            for (int p = 0; p < parts; ++p) fn(p);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            job_ = &fn;
-            parts_ = parts;
-            next_.store(0);
-            left_ = parts;
-            error_ = nullptr;
-            generation_.fetch_add(1, std::memory_order_release);
-        }
-        wake_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lock(m_);
-        done_.wait(lock, [this] { return left_ == 0; });
-        job_ = nullptr;
-        if (error_) std::rethrow_exception(error_);
-    }
-
-private:
-    void work() {
-        for (;;) {
-            const int p = next_.fetch_add(1);
-            if (p >= parts_) return;
-            std::exception_ptr err;
-            try {
-                (*job_)(p);
-            } catch (...) {
-                err = std::current_exception();
-            }
-            std::lock_guard<std::mutex> lock(m_);
-            if (err && !error_) error_ = err;
-            if (--left_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lock(m_);
-                wake_.wait(lock, [&] { return stop_.load() || generation_.load() != seen; });
-                if (stop_.load()) return;
-                seen = generation_.load();
-            }
-            work();
-        }
-    }
-
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable wake_, done_;
-    const std::function<void(int)> *job_ = nullptr;
-    std::atomic<int> next_{0};
-    int parts_ = 0, left_ = 0;
-    std::atomic<unsigned long long> generation_{0};
-    std::atomic<bool> stop_{false};
-    std::exception_ptr error_;
-};
-
 class Engine {
 public:
     struct LengthGroup {
@@ -347,6 +266,12 @@ public:
     void set_ragged_batching(int mode) {
         if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
         ragged_ = mode;
+    }
+    // Cap of the internal pointer scratch of compute_alignments in MiB (0: 64 GiB / half the free HBM); batches
+    // that need more run in chunks.  The environment's VALIGN_HIP_SCRATCH_CAP_MB (test switch) applies when this is 0.
+    void set_pointer_scratch_cap_mb(long long mb) {
+        if (mb < 0) throw std::runtime_error("pointer_scratch_cap_mb must be >= 0");
+        if (mb > 0) scratch_cap_mb_ = mb;
     }
     int device() const { return device_; }
     int read_length() const { return R_; }
@@ -977,7 +902,8 @@ public:
         const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_sets * row_dwords * 4;
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
-        const size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
+        size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
+        if (scratch_cap_mb_ > 0) cap = std::min<size_t>(cap, (size_t)scratch_cap_mb_ << 20);
         long long chunk = std::max<long long>(2, (long long)(cap / bytes_per_pp) * 2);
         chunk = std::min(chunk, (n + 1) / 2 * 2);
         const long long waves = chunk / 2;
@@ -1090,12 +1016,7 @@ public:
     // the ABI demands) meanwhile.
     // `alignments`: the ABI's Alignment array (rows become operator new[] blocks), or a FlatSink (caller-provided
     // contiguous buffers, for FFI callers that do not want 2n heap blocks)
-    struct FlatSink {
-        uint8_t *rows;            // n * 2 * (R+F) bytes
-        short *idx;               // n * 4
-        size_t AL;
-        FlatSink operator+(long long k) const { return FlatSink{rows + (size_t)k * 2 * AL, idx + 4 * k, AL}; }
-    };
+    using FlatSink = valign::FlatSink;      // host_pipeline.h
 
     template <typename Sink>
     void align_host(int opt, int n, const char *const *reads, const char *const *refs, Sink alignments,
@@ -1401,31 +1322,10 @@ private:
         align_staged_pairs_ = pairs;
     }
 
-    void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
-        const size_t AL = sink.AL;
-        for_ranges(threads, cnt, 2048, [&](int, long long lo, long long hi) {
-            memcpy(sink.rows + (size_t)lo * 2 * AL, rows + (size_t)lo * 2 * AL, (size_t)(hi - lo) * 2 * AL);
-            memcpy(sink.idx + 4 * lo, idx + 4 * lo, sizeof(short) * 4 * (size_t)(hi - lo));
-        });
-    }
-
-    template <typename AlignmentT>
-    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
-        const size_t AL = (size_t)R_ + F_;
-        auto work = [=](long long lo, long long hi) {
-            for (long long i = lo; i < hi; ++i) {
-                AlignmentT &a = alignments[i];
-                a.read = new char[AL ? AL : 1];
-                a.ref = new char[AL ? AL : 1];
-                memcpy(a.read, rows + (size_t)i * 2 * AL, AL);
-                memcpy(a.ref, rows + (size_t)i * 2 * AL + AL, AL);
-                a.readStart = idx[4 * i + 0];
-                a.readEnd = idx[4 * i + 1];
-                a.refStart = idx[4 * i + 2];
-                a.refEnd = idx[4 * i + 3];
-            }
-        };
-        for_ranges(threads, cnt, 2048, [&](int, long long lo, long long hi) { work(lo, hi); });
+    // gather / scatter between the caller's scattered blocks and the staging: host_pipeline.h (host-only, sanitizer-tested)
+    template <typename Sink>
+    void scatter(Sink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
+        packer_.scatter(sink, cnt, rows, idx, threads);
     }
 
     void release_staging() {
@@ -1539,19 +1439,9 @@ private:
         return len;
     }
 
-    // fn(part, lo, hi) over `threads` equal ranges of [0, cnt) on the persistent workers
     template <typename Fn>
     void for_ranges(int threads, long long cnt, long long serial_below, Fn fn) {
-        if (threads <= 1 || cnt < serial_below) {
-            fn(0, 0ll, cnt);
-            return;
-        }
-        if (!pool_ || pool_->workers() != threads - 1) pool_.reset(new WorkerPool(threads - 1));
-        const long long per = (cnt + threads - 1) / threads;
-        pool_->run(threads, [&](int t) {
-            const long long lo = t * per, hi = std::min(cnt, lo + per);
-            if (lo < hi) fn(t, lo, hi);
-        });
+        packer_.for_ranges(threads, cnt, serial_below, fn);
     }
 
     // Bin the chunk's pairs by trimmed length class, fold bins too small to be worth it into
@@ -1668,14 +1558,7 @@ private:
 
     void gather(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads,
                 uint8_t *dst_refs, int threads) {
-        const int R = R_, F = F_;
-        auto work = [=](long long lo, long long hi) {
-            for (long long i = lo; i < hi; ++i) {
-                memcpy(dst_reads + (size_t)i * R, reads[i], (size_t)R);
-                memcpy(dst_refs + (size_t)i * F, refs[i], (size_t)F);
-            }
-        };
-        for_ranges(threads, cnt, 4096, [&](int, long long lo, long long hi) { work(lo, hi); });
+        packer_.gather(reads, refs, cnt, dst_reads, dst_refs, threads);
     }
 
     int device_, R_, F_;
@@ -1694,7 +1577,7 @@ private:
     std::map<std::pair<int, int>, LaunchPlan> class_plans_;
     std::vector<unsigned short> bin_[kSlots];
     std::vector<int> pos_[kSlots];
-    std::unique_ptr<WorkerPool> pool_;
+    HostPacker packer_{R_, F_};                               // (declared after R_ / F_)
     bool slot_ragged_[kSlots] = {};
     HostStats host_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always

@@ -7,6 +7,7 @@
 #include "valign_hip.h"
 #include "versalign_plugin_abi.h"
 
+#include <atomic>
 #include <exception>
 #include <malloc.h>
 #include <memory>
@@ -67,26 +68,34 @@ public:
             sc.open_ref = sc.ext_ref = sc.gap_ref;
         }
         try {
-            engine_.reset(new valign::Engine(opt_param("hip_device", 0), R, F, sc, opt_param("hip_group_lanes", 0),
-                                             opt_param("hip_rows_per_lane", 0)));
-            engine_->set_traceback_policy(opt_param("traceback_policy", 0));
-            engine_->set_band_width(opt_param("band_width", 0));
-            engine_->set_score_width(opt_param("score_width", 0));
-            engine_->set_ragged_batching(opt_param("ragged_batching", 0));
             // hip_devices = N: the pairs of every call are split into N contiguous shards, one device each
-            // (hip_device, hip_device + 1, ... modulo the visible devices), each shard on its own host
-            // thread with its own streams and staging.  Results land in the caller's host arrays, so no
-            // collective is needed inside one process.
+            // (hip_device, hip_device + 1, ...), each shard on its own host thread with its own streams and
+            // staging.  Results land in the caller's host arrays, so no collective is needed inside one process.
             const int shards = opt_param("hip_devices", 1);
             if (shards < 1 || shards > 64) throw std::runtime_error("hip_devices must be 1..64");
             const int first = opt_param("hip_device", 0), visible = valign_hip_device_count();
-            for (int d = 1; d < shards; ++d) {
-                more_.emplace_back(new valign::Engine((first + d) % (visible > 0 ? visible : 1), R, F, sc,
-                                                      opt_param("hip_group_lanes", 0), opt_param("hip_rows_per_lane", 0)));
-                more_.back()->set_traceback_policy(opt_param("traceback_policy", 0));
-                more_.back()->set_band_width(opt_param("band_width", 0));
-                more_.back()->set_score_width(opt_param("score_width", 0));
-                more_.back()->set_ragged_batching(opt_param("ragged_batching", 0));
+            if (shards > 1 && first + shards > visible) {
+                // More shards than devices: several shards share a device (each with its own engine).  Results are
+                // the same, the speed-up is not there -- a host that asked for N devices should hear about it.
+                if (opt_param("hip_devices_strict", 0) != 0)
+                    throw std::runtime_error("hip_devices = " + std::to_string(shards) + " from device " + std::to_string(first) +
+                                             " but only " + std::to_string(visible) + " visible (hip_devices_strict)");
+                log_line(1, "hip_devices = " + std::to_string(shards) + " from device " + std::to_string(first) + " but only " +
+                                std::to_string(visible) + " visible: shards are folded onto the visible devices (same results, no "
+                                "speed-up; hip_devices_strict = 1 refuses instead)");
+            }
+            for (int d = 0; d < shards; ++d) {
+                std::unique_ptr<valign::Engine> e(new valign::Engine((first + d) % (visible > 0 ? visible : 1), R, F, sc,
+                                                                     opt_param("hip_group_lanes", 0), opt_param("hip_rows_per_lane", 0)));
+                e->set_traceback_policy(opt_param("traceback_policy", 0));
+                e->set_band_width(opt_param("band_width", 0));
+                e->set_score_width(opt_param("score_width", 0));
+                e->set_ragged_batching(opt_param("ragged_batching", 0));
+                // pointer scratch of compute_alignments (device memory, internal): capped at 64 GiB / half the free HBM
+                // unless the host says otherwise -- larger batches simply run in more chunks
+                e->set_pointer_scratch_cap_mb(opt_param("pointer_scratch_cap_mb", 0));
+                if (d == 0) engine_ = std::move(e);
+                else more_.push_back(std::move(e));
             }
             if (shards > 1) {
                 std::string where = std::to_string(engine_->device());
@@ -106,7 +115,9 @@ public:
             if (tuning == 1) mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
             if (tuning == 1 || tuning == 2) {
                 mallopt(M_TOP_PAD, 256 << 20);
-                log_line(0, std::string("host_malloc_tuning = ") + std::to_string(tuning) +
+                // a process-wide setting of the HOST's allocator: said out loud (WARNING level) the first time
+                static std::atomic<bool> told{false};
+                log_line(told.exchange(true) ? 0 : 1, std::string("host_malloc_tuning = ") + std::to_string(tuning) +
                                 ": mallopt(M_TOP_PAD, 256 MB)" + (tuning == 1 ? " + M_TRIM_THRESHOLD off" : "") +
                                 " for the result rows of compute_alignments (0 leaves the host's allocator alone)");
             }
@@ -292,6 +303,14 @@ VALIGN_EXPORT int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode)
         return 1;
     }
     return flat_guard([&] { e->impl->set_ragged_batching(mode); });
+}
+
+VALIGN_EXPORT int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_pointer_scratch_cap_mb(mb); });
 }
 
 VALIGN_EXPORT int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy) {

@@ -1,0 +1,196 @@
+// host_pipeline.h -- the host-only half of libHIPKernel.so's host-pointer path: the persistent worker pool and the
+// gather / scatter between the caller's scattered heap blocks (what the plugin ABI hands over: N `char *`, one per
+// sequence, src/util/versalignUtil.cpp:24-31; 2N operator new[] result rows, include/AlignmentKernel.h:20-23) and the
+// contiguous pair-major staging buffers the device works on.  The reference's precedent is the OpenCL backend's
+// gather / collect loops (src/Kernels/OpenCL/OpenCLKernel.cpp:57-66, 613-645: one memcpy per sequence, an OpenMP copy
+// back); nothing of them is reused.
+//
+// No HIP in here on purpose: this header compiles with plain g++ so that the code 16 host threads run concurrently
+// into caller-owned arrays is exercised under -fsanitize=thread / address,undefined on the CPU
+// (tests/host_pipeline_check.cpp, `make sanitize`); hip_engine.hip.h includes it unchanged.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace valign {
+
+// Host worker threads that outlive a call: gather / scatter run on them chunk after chunk (spawning
+// num_threads std::threads per chunk cost as much as the copying itself).  run(parts, fn) calls
+// fn(part) for every part in [0, parts) on the workers and the calling thread and returns when all
+// are done; an exception from fn is rethrown on the caller.
+class WorkerPool {
+public:
+    explicit WorkerPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    int workers() const { return (int)threads_.size(); }
+
+    void run(int parts, const std::function<void(int)> &fn) {
+        if (parts <= 0) return;
+        if (parts == 1 || threads_.empty()) {
+            for (int p = 0; p < parts; ++p) fn(p);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_ = &fn;
+            parts_ = parts;
+            next_ = 0;
+            left_ = parts;
+            error_ = nullptr;
+            ++generation_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this] { return left_ == 0 && busy_ == 0; });
+        job_ = nullptr;
+        if (error_) std::rethrow_exception(error_);
+    }
+
+private:
+    // Parts are claimed under the mutex (a part is thousands of pairs: the lock is nothing beside it).  `busy_` counts
+    // the threads inside work(): run() only returns -- and the job's std::function only dies -- once every worker has
+    // left it, so a worker that woke up late can never look at a job that is already gone.
+    void work() {
+        std::unique_lock<std::mutex> lock(m_);
+        if (!job_) return;
+        ++busy_;
+        for (;;) {
+            if (next_ >= parts_) break;
+            const int p = next_++;
+            const std::function<void(int)> *job = job_;
+            lock.unlock();
+            std::exception_ptr err;
+            try {
+                (*job)(p);
+            } catch (...) {
+                err = std::current_exception();
+            }
+            lock.lock();
+            if (err && !error_) error_ = err;
+            --left_;
+        }
+        --busy_;
+        if (left_ == 0 && busy_ == 0) done_.notify_all();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                wake_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)> *job_ = nullptr;     // everything below: guarded by m_
+    int next_ = 0, parts_ = 0, left_ = 0, busy_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+    std::exception_ptr error_;
+};
+
+// Caller-provided contiguous result buffers (valign_hip_align_host): rows = n * 2 * AL bytes, idx = n * 4 shorts
+struct FlatSink {
+    uint8_t *rows;
+    short *idx;
+    size_t AL;
+    FlatSink operator+(long long k) const { return FlatSink{rows + (size_t)k * 2 * AL, idx + 4 * k, AL}; }
+};
+
+// Gather / scatter of one engine: fixed (read_length, ref_length), a pool that is resized when the caller's
+// num_threads changes.  Threads write disjoint pair ranges; nothing else is shared.
+class HostPacker {
+public:
+    HostPacker(int R, int F) : R_(R), F_(F) {}
+
+    // fn(part, lo, hi) over `threads` equal ranges of [0, cnt) on the persistent workers
+    template <typename Fn>
+    void for_ranges(int threads, long long cnt, long long serial_below, Fn fn) {
+        if (threads <= 1 || cnt < serial_below) {
+            fn(0, 0ll, cnt);
+            return;
+        }
+        if (!pool_ || pool_->workers() != threads - 1) pool_.reset(new WorkerPool(threads - 1));
+        const long long per = (cnt + threads - 1) / threads;
+        pool_->run(threads, [&](int t) {
+            const long long lo = t * per, hi = std::min(cnt, lo + per);
+            if (lo < hi) fn(t, lo, hi);
+        });
+    }
+
+    // reads[i] (exactly R bytes) -> dst_reads + i * R, refs likewise: the pair-major layout of the device buffers
+    void gather(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads, uint8_t *dst_refs,
+                int threads) {
+        const int R = R_, F = F_;
+        for_ranges(threads, cnt, 4096, [=](int, long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                memcpy(dst_reads + (size_t)i * R, reads[i], (size_t)R);
+                memcpy(dst_refs + (size_t)i * F, refs[i], (size_t)F);
+            }
+        });
+    }
+
+    // staging -> the caller's contiguous buffers
+    void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
+        const size_t AL = sink.AL;
+        for_ranges(threads, cnt, 2048, [=](int, long long lo, long long hi) {
+            memcpy(sink.rows + (size_t)lo * 2 * AL, rows + (size_t)lo * 2 * AL, (size_t)(hi - lo) * 2 * AL);
+            memcpy(sink.idx + 4 * lo, idx + 4 * lo, sizeof(short) * 4 * (size_t)(hi - lo));
+        });
+    }
+
+    // staging -> the ABI's Alignment array: two fresh operator new[] rows per pair (the caller delete[]s them)
+    template <typename AlignmentT>
+    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
+        const size_t AL = (size_t)R_ + F_;
+        for_ranges(threads, cnt, 2048, [=](int, long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                AlignmentT &a = alignments[i];
+                a.read = new char[AL ? AL : 1];
+                a.ref = new char[AL ? AL : 1];
+                memcpy(a.read, rows + (size_t)i * 2 * AL, AL);
+                memcpy(a.ref, rows + (size_t)i * 2 * AL + AL, AL);
+                a.readStart = idx[4 * i + 0];
+                a.readEnd = idx[4 * i + 1];
+                a.refStart = idx[4 * i + 2];
+                a.refEnd = idx[4 * i + 3];
+            }
+        });
+    }
+
+private:
+    int R_, F_;
+    std::unique_ptr<WorkerPool> pool_;
+};
+
+}  // namespace valign

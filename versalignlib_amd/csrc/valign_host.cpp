@@ -8,7 +8,7 @@
 #include <string.h>
 
 #include <chrono>
-#include <fstream>
+#include <stdio.h>
 #include <map>
 #include <mutex>
 #include <new>
@@ -362,43 +362,57 @@ void vh_log_to_stderr(vh_plugin *p, int on) {
 
 int vh_parse_fasta(const char *path, char **blob, int *count) {
     if (!path || !blob || !count) return fail("null argument");
-    std::ifstream in(path);
-    if (!in.good()) return fail(std::string("cannot open ") + path);
-    // Same acceptance rules as the reference parser: a record starts at '>' and ends at
-    // the next '>' or blank line; a sequence line containing a space discards the record;
-    // only complete lines (terminated by '\n') are consumed.
-    std::vector<std::string> seqs;
-    std::string line, name, content;
-    while (std::getline(in, line).good()) {
-        if (line.empty() || line[0] == '>') {
-            if (!name.empty()) {
-                seqs.push_back(content);
-                name.clear();
-            }
-            if (!line.empty()) name = line.substr(1);
-            content.clear();
-        } else if (!name.empty()) {
-            if (line.find(' ') != std::string::npos) {
-                name.clear();
-                content.clear();
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(std::string("cannot open ") + path);
+    std::string text;
+    char chunk[1 << 16];
+    for (size_t got; (got = fread(chunk, 1, sizeof chunk, fp)) > 0;) text.append(chunk, got);
+    fclose(fp);
+    // One pass over the file image with a three-state record machine.  What is accepted is what the
+    // reference host accepts (src/util/versalignUtil.h:52-92, exercised by tests/test_host_and_abi.py):
+    // a header is '>' plus at least one byte; the record's sequence lines are joined until the next
+    // '>' line or an empty line; a sequence line with a blank in it voids the whole record; a final
+    // line without '\n' is not part of the file; a sequence ends at its first NUL byte.
+    enum { kOutside, kInRecord, kVoided } state = kOutside;
+    std::string packed;                  // the accepted sequences, each followed by its NUL
+    size_t record_at = 0;                // where the open record's sequence starts in `packed`
+    int records = 0;
+    auto close_record = [&] {
+        if (state == kInRecord) {
+            const size_t nul = packed.find('\0', record_at);
+            if (nul != std::string::npos) packed.resize(nul);
+            packed.push_back('\0');
+            ++records;
+        } else {
+            packed.resize(record_at);
+        }
+        state = kOutside;
+    };
+    const char *cursor = text.data(), *const stop = cursor + text.size();
+    while (cursor < stop) {
+        const char *nl = (const char *)memchr(cursor, '\n', (size_t)(stop - cursor));
+        if (!nl) break;
+        const size_t len = (size_t)(nl - cursor);
+        if (len == 0 || cursor[0] == '>') {
+            if (state != kOutside) close_record();
+            record_at = packed.size();
+            if (len > 1) state = kInRecord;           // (a bare ">" names nothing: its lines are skipped)
+        } else if (state == kInRecord) {
+            if (memchr(cursor, ' ', len)) {
+                packed.resize(record_at);
+                state = kVoided;
             } else {
-                content += line;
+                packed.append(cursor, len);
             }
         }
+        cursor = nl + 1;
     }
-    if (!name.empty()) seqs.push_back(content);
-    size_t total = 0;
-    for (auto &s : seqs) total += strlen(s.c_str()) + 1;   // strdup semantics: stop at NUL
-    char *out = (char *)malloc(total ? total : 1);
+    if (state != kOutside) close_record();
+    char *out = (char *)malloc(packed.size() ? packed.size() : 1);
     if (!out) return fail("out of memory");
-    size_t off = 0;
-    for (auto &s : seqs) {
-        size_t len = strlen(s.c_str());
-        memcpy(out + off, s.c_str(), len + 1);
-        off += len + 1;
-    }
+    memcpy(out, packed.data(), packed.size());
     *blob = out;
-    *count = (int)seqs.size();
+    *count = records;
     return 0;
 }
 
@@ -411,7 +425,7 @@ int vh_pad(const char *blob, int count, char fill, uint8_t **out, int *length) {
         if (len > longest) longest = len;
         s += len + 1;
     }
-    uint8_t *buf = (uint8_t *)malloc(longest * (size_t)count ? longest * (size_t)count : 1);
+    uint8_t *buf = (uint8_t *)malloc(longest > 0 && count > 0 ? longest * (size_t)count : 1);
     if (!buf) return fail("out of memory");
     s = blob;
     for (int i = 0; i < count; ++i) {

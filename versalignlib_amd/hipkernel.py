@@ -61,6 +61,7 @@ def lib():
         L.valign_hip_engine_destroy.argtypes = [vp]
         L.valign_hip_set_traceback_policy.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_band_width.argtypes = [vp, ctypes.c_int]
+        L.valign_hip_set_pointer_scratch_cap_mb.argtypes = [vp, ctypes.c_longlong]
         L.valign_hip_set_score_width.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_ragged_batching.argtypes = [vp, ctypes.c_int]
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
@@ -77,7 +78,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_set_traceback_policy", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -104,6 +105,11 @@ class Engine:
     def set_traceback_policy(self, policy):
         """0: Default-kernel tie-breaks (default); 1: SSE/AVX-kernel tie-breaks."""
         if lib().valign_hip_set_traceback_policy(self._h, int(policy)) != 0:
+            raise HipKernelError(_err())
+
+    def set_pointer_scratch_cap_mb(self, mb):
+        """Cap of compute_alignments' device-side pointer scratch in MiB (0: 64 GiB / half the free HBM)."""
+        if lib().valign_hip_set_pointer_scratch_cap_mb(self._h, int(mb)) != 0:
             raise HipKernelError(_err())
 
     def set_score_width(self, bits):
