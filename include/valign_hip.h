@@ -34,6 +34,8 @@
  *                                                         compute_alignments call from ~700 ms to ~50 ms;
  *                                                         1 also M_TRIM_THRESHOLD off; 0 touches nothing.
  *                                                         Logged at WARNING level the first time
+ *       host_packing .................................... score_alignments: 1 (default) sequences cross PCIe as 4-bit
+ *                                                         base classes (identical scores), 0 raw ASCII
  *       pointer_scratch_cap_mb .......................... cap of compute_alignments' device-side pointer
  *                                                         scratch in MiB (default 0: 64 GiB / half the free HBM)
  *       hip_device ...................................... device ordinal (default 0)
@@ -164,6 +166,20 @@ int valign_hip_score_host(valign_hip_engine *e, int opt, int n, const char *cons
  * compute_alignments without its 2n operator new[] blocks -- for FFI callers (ctypes, cgo, JNI).      */
 int valign_hip_align_host(valign_hip_engine *e, int opt, int n, const char *const *reads,
                           const char *const *refs, void *rows, short *idx, int threads);
+
+/* Page-lock a host range and map it for the device (hipHostRegister behind a C symbol, so that an FFI caller needs no
+ * HIP binding).  valign_hip_align_host into result buffers that lie inside a registered range -- or inside memory the
+ * caller page-locked itself -- skips the library's pinned staging and its host-side copy: the device's copy engine
+ * writes the caller's buffers directly (the flat layout IS the device layout).  Register once, reuse the buffers;
+ * registering costs about a second per GB.  Unregister (with the pointer given to register) before freeing the memory.   */
+int valign_hip_host_register(void *ptr, unsigned long long bytes);
+int valign_hip_host_unregister(void *ptr);
+
+/* Host-pointer score path (valign_hip_score_host / score_alignments): 1 (default) = the sequences cross PCIe as 4-bit
+ * base classes, two per byte, and are expanded to one canonical byte per class in device memory -- the kernels only
+ * ever look at the class of a base (DefaultKernel.h:43-60), so scores are identical; 0 = raw ASCII.  Plugin key:
+ * host_packing.  Alignments always travel as the caller's bytes (they are copied into the result rows).                 */
+int valign_hip_set_host_packing(valign_hip_engine *e, int mode);
 
 /* JSON description of what a call with this opt would launch (geometry, LDS, grid).   */
 int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap);

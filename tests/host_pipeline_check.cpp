@@ -102,9 +102,60 @@ void round_trip(int R, int F, long long n, int threads) {
     }
 }
 
+// 4-bit class packing: the vector form against the definition, every byte value at every position of the step
+void packing(int R, int F, long long n, int threads) {
+    std::vector<char *> reads((size_t)n), refs((size_t)n);
+    static const char alphabet[] = "ACGTNacgtn";
+    for (long long i = 0; i < n; ++i) {
+        reads[(size_t)i] = new char[R ? R : 1];
+        refs[(size_t)i] = new char[F ? F : 1];
+        for (int k = 0; k < R; ++k) {
+            const uint64_t r = mix((uint64_t)i * 977 + k);
+            reads[(size_t)i][k] = (r & 7) ? alphabet[(r >> 8) % 10] : (char)(r >> 16);      // one in eight: any byte
+        }
+        for (int k = 0; k < F; ++k) {
+            const uint64_t r = mix((uint64_t)i * 1031 + k + 3);
+            refs[(size_t)i][k] = (r & 7) ? alphabet[(r >> 8) % 10] : (char)(r >> 16);
+        }
+    }
+    const size_t PR = valign::packed_length(R), PF = valign::packed_length(F);
+    std::vector<uint8_t> pr((size_t)n * PR + 1, 0xEE), pf((size_t)n * PF + 1, 0xEE);
+    valign::HostPacker packer(R, F);
+    packer.gather_packed(reads.data(), refs.data(), n, pr.data(), pf.data(), threads);
+    bool ok = pr[(size_t)n * PR] == 0xEE && pf[(size_t)n * PF] == 0xEE;
+    for (long long i = 0; i < n && ok; ++i) {
+        for (int k = 0; k < R && ok; ++k)
+            ok = ((pr[(size_t)i * PR + k / 2] >> (4 * (k & 1))) & 15) == valign::base_class_of((uint8_t)reads[(size_t)i][k]);
+        for (int k = 0; k < F && ok; ++k)
+            ok = ((pf[(size_t)i * PF + k / 2] >> (4 * (k & 1))) & 15) == valign::base_class_of((uint8_t)refs[(size_t)i][k]);
+        if (R & 1) ok = ok && (pr[(size_t)i * PR + PR - 1] >> 4) == 0;            // the spare nibble of an odd length is 0
+        if (F & 1) ok = ok && (pf[(size_t)i * PF + PF - 1] >> 4) == 0;
+    }
+    expect(ok, "gather_packed " + std::to_string(R) + "x" + std::to_string(F) + " n=" + std::to_string(n));
+    for (long long i = 0; i < n; ++i) {
+        delete[] reads[(size_t)i];
+        delete[] refs[(size_t)i];
+    }
+}
+
 }  // namespace
 
 int main() {
+    {   // every byte value, scalar == vector == definition
+        uint8_t all[256 + 64], a[160], b[160];
+        for (int c = 0; c < 256 + 64; ++c) all[c] = (uint8_t)c;
+        valign::pack_classes(all, 256 + 64, a);
+        valign::pack_classes_scalar(all, 256 + 64, b);
+        bool ok = memcmp(a, b, 160) == 0;
+        for (int c = 0; c < 256 && ok; ++c) ok = ((a[c / 2] >> (4 * (c & 1))) & 15) == valign::base_class_of((uint8_t)c);
+        expect(ok, "pack_classes over every byte value");
+    }
+    packing(150, 500, 5003, 16);
+    packing(37, 101, 4097, 3);
+    packing(1, 33, 300, 1);
+    packing(64, 31, 4500, 16);
+    packing(0, 5, 10, 2);
+
     // chunk sizes around the serial thresholds (2048 / 4096), odd shapes, thread counts that resize the pool
     const long long counts[] = {0, 1, 2, 2047, 2048, 2049, 4095, 4096, 4097, 10007};
     const int threads[] = {1, 2, 3, 16, 5, 16};

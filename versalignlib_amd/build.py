@@ -74,24 +74,37 @@ def build_host(force=False):
     return HOST_LIB
 
 
+KERNEL_PART_DEPS = ["kernel_part.hip", "kernel_instances.hip.h", "dp_kernels.hip.h", "trace_kernels.hip.h"]
+
+
 def build_hip(force=False, extra_flags=(), jobs=None):
     """hipcc -c per translation unit (the main one + HIP_KERNEL_PARTS kernel parts) in parallel, then
-    one link.  A single hipcc run over all ~350 kernel instances takes minutes."""
+    one link.  A single hipcc run over all ~350 kernel instances takes minutes.  Units are rebuilt
+    one by one: the kernel parts only include the per-geometry kernel headers (KERNEL_PART_DEPS), so
+    a change to the engine or the plugin recompiles the main unit alone."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
-    deps = [os.path.join(CSRC, s) for s in HIP_DEPS] + [
-        os.path.join(INCLUDE, h) for h in ("valign_hip.h", "versalign_plugin_abi.h")]
-    if not (force or _newer(HIP_PLUGIN, deps)):
-        return HIP_PLUGIN
+    headers = [os.path.join(INCLUDE, h) for h in ("valign_hip.h", "versalign_plugin_abi.h")]
+    all_deps = [os.path.join(CSRC, s) for s in HIP_DEPS] + headers
+    part_deps = [os.path.join(CSRC, s) for s in KERNEL_PART_DEPS]
+    flags = list(extra_flags)
+    stamp = os.path.join(OBJ, "flags.txt")             # objects built with other flags are stale
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
     common = [hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-pthread", "-Wall",
-              "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
-    units = [(os.path.join(CSRC, src), os.path.join(OBJ, os.path.splitext(src)[0] + ".o"), []) for src in HIP_SOURCES]
-    units += [(os.path.join(CSRC, HIP_KERNEL_PART), os.path.join(OBJ, "kernel_part%d.o" % i), ["-DVALIGN_PART=%d" % i])
+              "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC] + flags
+    units = [(os.path.join(CSRC, src), os.path.join(OBJ, os.path.splitext(src)[0] + ".o"), [], all_deps) for src in HIP_SOURCES]
+    units += [(os.path.join(CSRC, HIP_KERNEL_PART), os.path.join(OBJ, "kernel_part%d.o" % i), ["-DVALIGN_PART=%d" % i], part_deps)
               for i in range(HIP_KERNEL_PARTS)]
-    jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
+    todo = [u for u in units if force or _newer(u[1], u[3])]
+    if not todo and not _newer(HIP_PLUGIN, [u[1] for u in units]):
+        return HIP_PLUGIN
+    jobs = jobs or max(1, min(len(todo) or 1, os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        list(pool.map(lambda u: _run(common + u[2] + ["-c", u[0], "-o", u[1]]), units))
+        list(pool.map(lambda u: _run(common + u[2] + ["-c", u[0], "-o", u[1]]), todo))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + [u[1] for u in units] + ["-o", HIP_PLUGIN])
     return HIP_PLUGIN
 

@@ -27,6 +27,7 @@
 #include "host_pipeline.h"
 #include "kernel_instances.hip.h"
 #include "long_kernels.hip.h"
+#include "pack_kernels.hip.h"
 #include "strip_kernels.hip.h"
 
 namespace valign {
@@ -172,6 +173,150 @@ struct LaunchPlan {
     int pairs_per_wave = 0;
 };
 
+// Issues the device-to-host result copies of align_host from a thread of its own, each one only after the HOST has seen
+// its chunk's kernels finish.  Why not simply hipStreamWaitEvent + hipMemcpyAsync: measured on this stack (rocprofv3,
+// profiles/r03_d2h_engine.txt), a D2H copy enqueued behind a still-pending barrier or kernel in its stream is carried out
+// by a shader (__amd_rocclr_copyBuffer) instead of the SDMA engine -- and that blit kernel, waiting on PCIe, sits on
+// the same CUs as the fill kernel of the next chunk: the fills of a 16-chunk call took 1.75x as long.  A copy issued
+// into a stream whose previous command is a finished copy goes to SDMA and costs the kernels nothing.
+class CopyIssuer {
+public:
+    struct Job {
+        hipEvent_t ready;           // the chunk's last kernel (waited for on the host)
+        void *dst[2];
+        const void *src[2];
+        size_t bytes[2];
+        hipStream_t stream;
+        hipEvent_t done;            // recorded behind the copies
+        int slot;
+    };
+    explicit CopyIssuer(int device) : device_(device), thread_([this] { loop(); }) {}
+    ~CopyIssuer() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        thread_.join();
+    }
+    void submit(const Job &job) {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            if (error_) std::rethrow_exception(error_);
+            jobs_.push_back(job);
+            ++submitted_[job.slot];
+        }
+        cv_.notify_all();
+    }
+    // every job submitted for `slot` has been issued: its `done` event is recorded and may be waited for
+    void wait_issued(int slot) {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return issued_[slot] == submitted_[slot] || error_; });
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            jobs_.clear();
+            for (int s = 0; s < 16; ++s) issued_[s] = submitted_[s];
+            std::rethrow_exception(e);
+        }
+    }
+    void wait_idle() {
+        for (int s = 0; s < 16; ++s) wait_issued(s);
+    }
+
+private:
+    void loop() {
+        (void)hipSetDevice(device_);
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return stop_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;          // (stop requested and nothing left)
+                job = jobs_.front();
+                jobs_.erase(jobs_.begin());
+            }
+            std::exception_ptr err;
+            try {
+                hip_check(hipEventSynchronize(job.ready), "hipEventSynchronize(kernels of the chunk)");
+                for (int k = 0; k < 2; ++k)
+                    if (job.bytes[k])
+                        hip_check(hipMemcpyAsync(job.dst[k], job.src[k], job.bytes[k], hipMemcpyDeviceToHost, job.stream), "D2H results");
+                hip_check(hipEventRecord(job.done, job.stream), "hipEventRecord");
+            } catch (...) {
+                err = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (err && !error_) error_ = err;
+                ++issued_[job.slot];
+            }
+            cv_.notify_all();
+        }
+    }
+    int device_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<Job> jobs_;
+    long long submitted_[16] = {}, issued_[16] = {};
+    bool stop_ = false;
+    std::exception_ptr error_;
+    std::thread thread_;            // last: starts when everything above exists
+};
+
+// Host memory the caller registered with valign_hip_host_register (page-locked and mapped for the device): result
+// buffers of valign_hip_align_host that lie inside such a range receive their rows straight from the device's copy
+// engine -- no pinned staging, no host-side copy.  Process-wide; ranges do not overlap.
+class HostRegistry {
+public:
+    static HostRegistry &instance() {
+        static HostRegistry r;
+        return r;
+    }
+    void add(void *ptr, size_t bytes) {
+        if (!ptr || bytes == 0) throw std::runtime_error("valign_hip_host_register: empty range");
+        std::lock_guard<std::mutex> lock(m_);
+        const uintptr_t lo = (uintptr_t)ptr, hi = lo + bytes;
+        for (const auto &r : ranges_)
+            if (lo < r.second && r.first < hi) throw std::runtime_error("valign_hip_host_register: overlaps a registered range");
+        hip_check(hipHostRegister(ptr, bytes, hipHostRegisterDefault), "hipHostRegister");
+        ranges_[lo] = hi;
+    }
+    void remove(void *ptr) {
+        std::lock_guard<std::mutex> lock(m_);
+        auto it = ranges_.find((uintptr_t)ptr);
+        if (it == ranges_.end()) throw std::runtime_error("valign_hip_host_unregister: not the start of a registered range");
+        hip_check(hipHostUnregister(ptr), "hipHostUnregister");
+        ranges_.erase(it);
+    }
+    // [ptr, ptr + bytes) is page-locked: registered here, or by the caller's own hipHostRegister / hipHostMalloc
+    bool covers(const void *ptr, size_t bytes) {
+        if (!ptr || bytes == 0) return false;
+        const uintptr_t lo = (uintptr_t)ptr, hi = lo + bytes;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            auto it = ranges_.upper_bound(lo);
+            if (it != ranges_.begin()) {
+                --it;
+                if (it->first <= lo && hi <= it->second) return true;
+            }
+        }
+        for (const void *probe : {ptr, (const void *)(hi - 1)}) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, probe) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            if (attr.type != hipMemoryTypeHost) return false;
+        }
+        return true;
+    }
+
+private:
+    std::mutex m_;
+    std::map<uintptr_t, uintptr_t> ranges_;      // start -> end
+};
+
 class Engine {
 public:
     struct LengthGroup {
@@ -184,6 +329,8 @@ public:
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
         double classify_ms = 0;                              // part of gather_ms: trimmed lengths + binning
+        int packed = 0;                                      // 1: the sequences crossed PCIe as 4-bit classes
+        int direct_out = 0;                                  // 1: results were copied straight into the caller's (registered) buffers
         int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly; 2: ... in one fused launch
     };
 
@@ -213,11 +360,12 @@ public:
         for (int s = 0; s < kSlots; ++s) {
             hip_check(hipEventCreateWithFlags(&slot_done_[s], hipEventDisableTiming), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&in_done_[s], hipEventDisableTiming), "hipEventCreate");
-            hip_check(hipEventCreateWithFlags(&kernels_done_[s], hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&kernels_done_[s], hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate");     // (the copy issuer sleeps on it)
         }
     }
 
     ~Engine() {
+        copy_issuer_.reset();               // (joins its thread; nothing is queued outside a call)
         (void)hipSetDevice(device_);
         if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
         release_staging();
@@ -266,6 +414,12 @@ public:
     void set_ragged_batching(int mode) {
         if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
         ragged_ = mode;
+    }
+    // 4-bit base classes instead of ASCII on the host-pointer score path (host_pipeline.h / pack_kernels.hip.h): 1 on
+    // (default), 0 off.  Identical scores; half the bytes across PCIe.
+    void set_host_packing(int mode) {
+        if (mode != 0 && mode != 1) throw std::runtime_error("host_packing must be 0 or 1");
+        pack_ = mode == 1;
     }
     // Cap of the internal pointer scratch of compute_alignments in MiB (0: 64 GiB / half the free HBM); batches
     // that need more run in chunks.  The environment's VALIGN_HIP_SCRATCH_CAP_MB (test switch) applies when this is 0.
@@ -362,6 +516,20 @@ public:
                   "hipLaunchKernel(score_kernel)");
     }
 
+
+    // n sequences of `len` 4-bit classes -> n * len canonical bytes (pack_kernels.hip.h)
+    void launch_unpack(const uint8_t *d_packed, uint8_t *d_out, long long n, int len, hipStream_t stream) {
+        if (n <= 0 || len <= 0) return;
+        UnpackArgs a{d_packed, d_out, n, len};
+        void *kargs[] = {&a};
+        const bool even = (len & 1) == 0;
+        const long long items = even ? (n * (long long)(len / 2) + 7) / 8 : n * (long long)((len + 1) / 2);
+        const long long blocks = (items + 255) / 256;
+        if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
+        hip_check(hipLaunchKernel(even ? (const void *)&unpack_even_kernel : (const void *)&unpack_odd_kernel, dim3((unsigned)blocks),
+                                  dim3(256), kargs, 0, stream),
+                  "hipLaunchKernel(unpack_kernel)");
+    }
 
     // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
     void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
@@ -582,8 +750,12 @@ public:
             slot_pending_[s] = 0;
         };
         int slot = 0;
-        for (long long begin = 0; begin < n; begin += chunk, slot = (slot + 1) % kSlots) {
-            const long long cnt = std::min<long long>(chunk, n - begin);
+        // Ramp: the device idles until the first chunk is gathered and copied, so the first chunks are short (a quarter,
+        // then half a chunk); chunks of many calls deep in the pipeline stay large (fewer launches, full waves).
+        long long chunk_no = 0, cnt = 0;
+        for (long long begin = 0; begin < n; begin += cnt, slot = (slot + 1) % kSlots, ++chunk_no) {
+            const long long ramp = (ramp_ && n > 2 * chunk) ? (chunk_no == 0 ? chunk / 4 : (chunk_no == 1 ? chunk / 2 : chunk)) : chunk;
+            cnt = std::min<long long>(std::max<long long>(ramp, 1024), n - begin);
             auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
             auto t1 = std::chrono::steady_clock::now();
@@ -615,6 +787,17 @@ public:
                 }
                 for (const LengthGroup &g : groups) host_stats_.cells_swept += (double)g.pairs * g.R * g.F;
                 host_stats_.cells_padded += (double)cnt * R_ * F_;
+            } else if (pack_) {
+                // two base classes per byte across PCIe, expanded in HBM to the canonical byte of each class
+                const size_t PR = packed_length(R_), PF = packed_length(F_);
+                packer_.gather_packed(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
+                host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
+                hip_check(hipMemcpyAsync(d_pack_reads_[slot], h_reads_[slot], (size_t)cnt * PR, hipMemcpyHostToDevice, st), "H2D reads (classes)");
+                hip_check(hipMemcpyAsync(d_pack_refs_[slot], h_refs_[slot], (size_t)cnt * PF, hipMemcpyHostToDevice, st), "H2D refs (classes)");
+                launch_unpack(d_pack_reads_[slot], d_reads_[slot], cnt, R_, st);
+                launch_unpack(d_pack_refs_[slot], d_refs_[slot], cnt, F_, st);
+                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+                host_stats_.packed = 1;
             } else {
                 gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
                 host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
@@ -645,17 +828,28 @@ public:
     // Device-resident batch -> rows (n * 2 * (R+F) bytes: read row then ref row, right-justified,
     // zero before the start, NUL at R+F-1) and idx (n * 4 shorts).  Asynchronous on `stream`;
     // the pointer scratch is reused chunk after chunk in stream order.
-    void align_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
-                      short *d_idx, hipStream_t stream) {
+    // `chain` (the chunk pipeline of align_host): the batch is ONE chunk of a sequence of calls.  Its traceback then runs on
+    // the engine's helper stream behind the fill, in region `chain->region` (0 / 1) of a pointer scratch sized for two chunks
+    // of `chain->chunk_pairs` pairs, and `stream` does NOT wait for it -- the fill of the next chunk (other region) runs
+    // beside this walk; the caller chains whatever needs the rows behind trace_done(region).  Returns false where the call
+    // ran in stream order instead (row strips, a chunk larger than half the scratch cap): everything is then on `stream`.
+    struct WalkChain {
+        int region;
+        long long chunk_pairs;
+    };
+    hipEvent_t trace_done(int region) const { return trace_done_[region]; }
+
+    bool align_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
+                      short *d_idx, hipStream_t stream, const WalkChain *chain = nullptr) {
         const int alg = opt & 0xF;
-        if (alg > 1 || n <= 0) return;
+        if (alg > 1 || n <= 0) return false;
         check_int16_range(alg);
         if (alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000))
             throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         if (plan_.long_mode) {
             align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
-            return;
+            return false;
         }
         const int G = plan_.geo->G, K = plan_.geo->K, AL = R_ + F_;
         // affine gaps with the traceback information tagged into the cells (4-bit codes, 4-step blocks)
@@ -673,7 +867,10 @@ public:
         if (scratch_cap_mb_ > 0) cap = std::min<size_t>(cap, (size_t)scratch_cap_mb_ << 20);
         long long chunk = (long long)(cap / bytes_per_pp) * 2;
         chunk = std::max(ppb, chunk / ppb * ppb);
-        chunk = std::min(chunk, (n + ppb - 1) / ppb * ppb);
+        const long long chain_pairs = chain ? (std::max(chain->chunk_pairs, n) + ppb - 1) / ppb * ppb : 0;
+        if (chain && (2 * chain_pairs > chunk || no_overlap_)) chain = nullptr;        // two regions do not fit: stream order
+        if (!chain) chain_regions_busy_[0] = chain_regions_busy_[1] = false;
+        chunk = chain ? 2 * chain_pairs : std::min(chunk, (n + ppb - 1) / ppb * ppb);
         ensure_trace_scratch(chunk, bytes_per_pp, stream);
         if (sse_policy_ && sc_.affine)
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
@@ -701,8 +898,10 @@ public:
         // that needs several chunks alternates between the two halves of the scratch.
         struct Part { long long begin, cnt, slot; int region; };
         std::vector<Part> parts;
-        const bool overlap = !no_overlap_ && (double)n * R_ * F_ >= 1e10;
-        if (overlap && chunk >= n && n >= 16 * ppb) {
+        const bool overlap = !no_overlap_ && (double)n * R_ * F_ >= 1e10 && !chain;
+        if (chain) {
+            parts.push_back(Part{0, n, chain->region * chain_pairs, chain->region});
+        } else if (overlap && chunk >= n && n >= 16 * ppb) {
             const long long big = std::max(ppb, n * 7 / 8 / ppb * ppb);
             parts.push_back(Part{0, big, 0, 0});
             parts.push_back(Part{big, n - big, big, 1});
@@ -713,18 +912,22 @@ public:
         } else {
             for (long long begin = 0; begin < n; begin += chunk) parts.push_back(Part{begin, std::min(chunk, n - begin), 0, 0});
         }
-        const bool helper = parts.size() > 1 && overlap;
-        if (helper) {
+        const bool helper = (parts.size() > 1 && overlap) || chain;
+        if (chain) {
+            // rows are zeroed on the helper stream right before the walk that writes them (the caller has made sure the
+            // previous user of d_rows is done: its copy-out event was waited for on the host)
+            ensure_trace_stream();
+        } else if (helper) {
             // the result rows are zeroed on the helper stream too (1.4 GB per million pairs of 150 x 500: the fills do not
             // touch them), behind whatever the caller's stream was still doing with them
             ensure_trace_stream();
             hip_check(hipEventRecord(entry_ev_, stream), "hipEventRecord");
             hip_check(hipStreamWaitEvent(trace_stream_, entry_ev_, 0), "hipStreamWaitEvent");
             hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, trace_stream_), "hipMemsetAsync(rows)");
-        } else {
+        } else if (!chain) {
             hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
         }
-        bool region_used[2] = {false, false};
+        bool region_used[2] = {chain && chain_regions_busy_[0], chain && chain_regions_busy_[1]};
         for (const Part &part : parts) {
             const long long begin = part.begin, cnt = part.cnt;
             unsigned *part_ptr = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(d_ptr_) + (size_t)(part.slot / 2) * bytes_per_pp);
@@ -788,6 +991,7 @@ public:
                 hip_check(hipEventRecord(fill_done_[part.region], stream), "hipEventRecord");
                 hip_check(hipStreamWaitEvent(trace_stream_, fill_done_[part.region], 0), "hipStreamWaitEvent");
                 walk_stream = trace_stream_;
+                if (chain) hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, trace_stream_), "hipMemsetAsync(rows)");
             }
             hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
                                       targs, 0, walk_stream),
@@ -797,9 +1001,14 @@ public:
                 region_used[part.region] = true;
             }
         }
+        if (chain) {                                       // the walk is the caller's to wait for (trace_done(region))
+            chain_regions_busy_[chain->region] = true;
+            return true;
+        }
         if (helper)                                        // the call stays asynchronous on `stream`: it ends when the walks have
             for (int r = 0; r < 2; ++r)
                 if (region_used[r]) hip_check(hipStreamWaitEvent(stream, trace_done_[r], 0), "hipStreamWaitEvent");
+        return false;
     }
 
     void ensure_trace_stream() {
@@ -1071,17 +1280,34 @@ public:
             host_stats_.direct = 1;
             return;
         }
+        // A flat destination in page-locked memory (valign_hip_host_register) IS the device layout: the copy engine
+        // writes the caller's buffers directly and the host has nothing left to scatter.
+        uint8_t *direct_rows = nullptr;
+        short *direct_idx = nullptr;
+        if (!no_direct_out_) flat_destination(alignments, n, direct_rows, direct_idx);
+        host_stats_.direct_out = direct_rows ? 1 : 0;
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
-            const auto t0 = std::chrono::steady_clock::now();
-            scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
-            host_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
+            if (!direct_rows) {
+                const auto t0 = std::chrono::steady_clock::now();
+                scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
+                host_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
+            }
             slot_pending_[s] = 0;
         };
         int slot = 0;
+        long long chunk_no = 0;
+        chain_regions_busy_[0] = chain_regions_busy_[1] = false;       // (every earlier call ended with its walks waited for)
+        prime_copy_engines(copy_in, copy_out, chunk);
+        CopyIssuer *copy_issuer = nullptr;
+        if (!d2h_on_stream_) {
+            if (!copy_issuer_) copy_issuer_.reset(new CopyIssuer(device_));
+            copy_issuer = copy_issuer_.get();
+        }
         for (long long begin = 0; begin < n; begin += chunk, slot = (slot + 1) % kSlots) {
             const long long cnt = std::min<long long>(chunk, n - begin);
             auto t0 = std::chrono::steady_clock::now();
+            if (copy_issuer) copy_issuer->wait_issued(slot);             // (only then is the slot's event the one of its last chunk)
             hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");   // its last chunk is back on the host
             host_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(slot);
@@ -1092,18 +1318,30 @@ public:
             hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, copy_in), "H2D refs");
             hip_check(hipEventRecord(in_done_[slot], copy_in), "hipEventRecord");
             hip_check(hipStreamWaitEvent(kernels, in_done_[slot], 0), "hipStreamWaitEvent");
-            align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], kernels);
-            hip_check(hipEventRecord(kernels_done_[slot], kernels), "hipEventRecord");
-            hip_check(hipStreamWaitEvent(copy_out, kernels_done_[slot], 0), "hipStreamWaitEvent");
-            hip_check(hipMemcpyAsync(h_rows_[slot], d_rows_[slot], (size_t)cnt * 2 * AL, hipMemcpyDeviceToHost, copy_out), "D2H rows");
-            hip_check(hipMemcpyAsync(h_idx_[slot], d_idx_[slot], sizeof(short) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, copy_out), "D2H idx");
-            hip_check(hipEventRecord(slot_done_[slot], copy_out), "hipEventRecord");
+            // the walk of this chunk runs on the helper stream beside the fill of the next one (two scratch regions)
+            const WalkChain chain{(int)(chunk_no & 1), chunk};
+            const bool chained = align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], kernels, &chain);
+            hip_check(hipEventRecord(kernels_done_[slot], chained ? trace_stream_ : kernels), "hipEventRecord");      // the chunk's last kernel
+            ++chunk_no;
+            uint8_t *rows_to = direct_rows ? direct_rows + (size_t)begin * 2 * AL : h_rows_[slot];
+            short *idx_to = direct_idx ? direct_idx + 4 * begin : h_idx_[slot];
+            if (copy_issuer) {
+                // SDMA, not a blit kernel beside the next fill: the copies are issued once the host has seen the kernels end
+                copy_issuer->submit(CopyIssuer::Job{kernels_done_[slot], {rows_to, idx_to}, {d_rows_[slot], d_idx_[slot]},
+                                                    {(size_t)cnt * 2 * AL, sizeof(short) * 4 * (size_t)cnt}, copy_out, slot_done_[slot], slot});
+            } else {
+                hip_check(hipStreamWaitEvent(copy_out, kernels_done_[slot], 0), "hipStreamWaitEvent");
+                hip_check(hipMemcpyAsync(rows_to, d_rows_[slot], (size_t)cnt * 2 * AL, hipMemcpyDeviceToHost, copy_out), "D2H rows");
+                hip_check(hipMemcpyAsync(idx_to, d_idx_[slot], sizeof(short) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, copy_out), "D2H idx");
+                hip_check(hipEventRecord(slot_done_[slot], copy_out), "hipEventRecord");
+            }
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;
         }
         for (int k = 0; k < kSlots; ++k) {              // oldest chunk first
             const int s = (slot + k) % kSlots;
             const auto t0 = std::chrono::steady_clock::now();
+            if (copy_issuer) copy_issuer->wait_issued(s);
             hip_check(hipEventSynchronize(slot_done_[s]), "hipEventSynchronize");
             host_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(s);
@@ -1126,13 +1364,13 @@ public:
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
                  "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
                  plan_.long_mode ? 1 : 0, band_width_, ragged_, host_stats_.launches,
                  host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
-                 score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+                 score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.packed, host_stats_.direct_out, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
                  host_stats_.drain_ms);
         return buf;
     }
@@ -1234,6 +1472,42 @@ private:
         return direct_bytes_ > 0 && (size_t)n * per_pair <= direct_bytes_ && n <= staged_pairs_;
     }
 
+    // Input copies (H2D) and result copies (D2H) of align_host must not share an SDMA engine: 0.65 GB in and 1.36 GB out
+    // per million pairs of 150 x 500 would queue up behind each other (36 ms of copying beside 28 ms of kernels).
+    // The runtime gives a stream the lowest-numbered engine that is FREE at the stream's first copy and keeps it there
+    // (AMD_LOG_LEVEL=4: "Last copy mask 0x1" on both streams, profiles/r03_copy_engines.txt) -- and at the start of a
+    // pipeline the first result copy finds the input engine idle.  So, once per engine: a small result copy is issued
+    // while a long input copy keeps engine 0 busy, which lands the result stream on the next engine for good.  No
+    // API promises this; where it does not work the only loss is the overlap.
+    void prime_copy_engines(hipStream_t copy_in, hipStream_t copy_out, long long staged_pairs) {
+        if (copy_engines_primed_ || no_engine_priming_) return;
+        copy_engines_primed_ = true;
+        const size_t in_bytes = std::min<size_t>((size_t)staged_pairs * F_, 128u << 20);
+        const size_t out_bytes = std::min<size_t>(sizeof(short) * 4 * (size_t)staged_pairs, 4096);
+        if (in_bytes < (16u << 20) || out_bytes == 0) return;         // (too short to still be running when the second copy is issued)
+        hip_check(hipStreamSynchronize(copy_in), "hipStreamSynchronize");
+        hip_check(hipStreamSynchronize(copy_out), "hipStreamSynchronize");
+        hip_check(hipMemcpyAsync(d_refs_[0], h_refs_[0], in_bytes, hipMemcpyHostToDevice, copy_in), "H2D (engine priming)");
+        // the input copy must have reached its engine before the result stream asks which engines are free: >= 16 MB
+        // take >= 0.3 ms on the wire, a tenth of that is plenty for the submission
+        for (const auto t0 = std::chrono::steady_clock::now(); ms_between(t0, std::chrono::steady_clock::now()) < 0.1;) {
+        }
+        hip_check(hipMemcpyAsync(h_idx_[0], d_idx_[0], out_bytes, hipMemcpyDeviceToHost, copy_out), "D2H (engine priming)");
+        hip_check(hipStreamSynchronize(copy_out), "hipStreamSynchronize");
+        hip_check(hipStreamSynchronize(copy_in), "hipStreamSynchronize");
+    }
+
+    // the caller's result buffers, when they can take the device's copies directly (page-locked, contiguous)
+    void flat_destination(FlatSink sink, long long n, uint8_t *&rows, short *&idx) const {
+        if (HostRegistry::instance().covers(sink.rows, (size_t)n * 2 * sink.AL) &&
+            HostRegistry::instance().covers(sink.idx, sizeof(short) * 4 * (size_t)n)) {
+            rows = sink.rows;
+            idx = sink.idx;
+        }
+    }
+    template <typename AlignmentT>
+    void flat_destination(AlignmentT *, long long, uint8_t *&, short *&) const {}      // 2n heap rows: always scattered
+
     // device-side address of pinned host memory of this engine (hipHostMalloc: mapped, same address on ROCm)
     static uint8_t *dev_view(void *pinned) {
         void *d = nullptr;
@@ -1248,6 +1522,13 @@ private:
         bool stale = false;
         for (int s = 0; s < kSlots; ++s) stale = stale || slot_pending_[s] != 0;
         if (!stale) return;
+        if (copy_issuer_) {
+            try {
+                copy_issuer_->wait_idle();
+            } catch (...) {
+            }
+        }
+        if (trace_stream_) (void)hipStreamSynchronize(trace_stream_);
         for (int s = 0; s < kSlots; ++s) {
             (void)hipStreamSynchronize(streams_[s]);
             slot_pending_[s] = 0;
@@ -1288,6 +1569,8 @@ private:
         const size_t need = (size_t)(waves * (ppw / 2)) * bytes_per_pp;
         if (need <= trace_bytes_ && pairs <= trace_pairs_) return;
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // nothing may still read the old scratch
+        if (trace_stream_) hip_check(hipStreamSynchronize(trace_stream_), "hipStreamSynchronize");
+        chain_regions_busy_[0] = chain_regions_busy_[1] = false;
         if (need > trace_bytes_) {
             if (d_ptr_) (void)hipFree(d_ptr_);
             d_ptr_ = nullptr;
@@ -1336,6 +1619,9 @@ private:
             if (d_reads_[s]) (void)hipFree(d_reads_[s]);
             if (d_refs_[s]) (void)hipFree(d_refs_[s]);
             if (d_scores_[s]) (void)hipFree(d_scores_[s]);
+            if (d_pack_reads_[s]) (void)hipFree(d_pack_reads_[s]);
+            if (d_pack_refs_[s]) (void)hipFree(d_pack_refs_[s]);
+            d_pack_reads_[s] = d_pack_refs_[s] = nullptr;
             h_reads_[s] = h_refs_[s] = nullptr;
             h_scores_[s] = nullptr;
             d_reads_[s] = d_refs_[s] = nullptr;
@@ -1356,6 +1642,9 @@ private:
             hip_check(hipMalloc((void **)&d_reads_[s], std::max<size_t>((size_t)pairs * R_, 16)), "hipMalloc");
             hip_check(hipMalloc((void **)&d_refs_[s], std::max<size_t>((size_t)pairs * F_, 16)), "hipMalloc");
             hip_check(hipMalloc((void **)&d_scores_[s], sizeof(short) * (size_t)pairs), "hipMalloc");
+            // (the 4-bit class copies of the score path; the pinned staging above is large enough for them)
+            hip_check(hipMalloc((void **)&d_pack_reads_[s], std::max<size_t>((size_t)pairs * packed_length(R_), 16)), "hipMalloc");
+            hip_check(hipMalloc((void **)&d_pack_refs_[s], std::max<size_t>((size_t)pairs * packed_length(F_), 16)), "hipMalloc");
         }
         staged_pairs_ = pairs;
     }
@@ -1585,9 +1874,16 @@ private:
     bool no_f16_ = getenv("VALIGN_HIP_NO_F16") != nullptr;   // tuning switch: int16 cells for symmetric affine SW too
     bool no_fused_ = getenv("VALIGN_HIP_NO_FUSED") != nullptr;   // tuning switch: small alignment calls as fill + traceback kernels
     bool no_prof_key_ = getenv("VALIGN_HIP_NO_PROF_KEY") != nullptr;   // tuning switch: compute the SW lane key instead of carrying it in the profile
+    bool copy_engines_primed_ = false;
+    bool no_engine_priming_ = getenv("VALIGN_HIP_NO_ENGINE_PRIMING") != nullptr;   // tuning switch
+    bool d2h_on_stream_ = getenv("VALIGN_HIP_D2H_ON_STREAM") != nullptr;   // tuning switch: result copies behind a stream wait (a blit kernel on this stack)
+    std::unique_ptr<CopyIssuer> copy_issuer_;
+    bool ramp_ = getenv("VALIGN_HIP_NO_RAMP") == nullptr;                 // tuning switch: every chunk of a host-pointer call full-sized
+    bool no_direct_out_ = getenv("VALIGN_HIP_NO_DIRECT_OUT") != nullptr;   // tuning switch: stage + scatter even into registered result buffers
     bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch
     hipStream_t trace_stream_ = nullptr;                          // helper stream of align_device (walks beside the next fill)
+    bool chain_regions_busy_[2] = {false, false};                 // WalkChain: the region's last walk may still be running
     hipEvent_t fill_done_[2] = {nullptr, nullptr}, trace_done_[2] = {nullptr, nullptr}, entry_ev_ = nullptr;
     std::string arch_;
     LaunchPlan plan_, latency_plan_;
@@ -1598,6 +1894,8 @@ private:
     uint8_t *h_reads_[kSlots] = {}, *h_refs_[kSlots] = {};
     short *h_scores_[kSlots] = {};
     uint8_t *d_reads_[kSlots] = {}, *d_refs_[kSlots] = {};
+    uint8_t *d_pack_reads_[kSlots] = {}, *d_pack_refs_[kSlots] = {};     // 4-bit classes as they arrive (score path)
+    bool pack_ = getenv("VALIGN_HIP_NO_PACK") == nullptr;                // host_packing (tuning switch: ASCII across PCIe)
     int16_t *d_scores_[kSlots] = {};
     // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
     unsigned *d_brow_ = nullptr;       // long-read path: strip boundary rows

@@ -94,6 +94,7 @@ public:
                 // pointer scratch of compute_alignments (device memory, internal): capped at 64 GiB / half the free HBM
                 // unless the host says otherwise -- larger batches simply run in more chunks
                 e->set_pointer_scratch_cap_mb(opt_param("pointer_scratch_cap_mb", 0));
+                if (Parameters.has_key("host_packing")) e->set_host_packing(Parameters.param_int("host_packing"));
                 if (d == 0) engine_ = std::move(e);
                 else more_.push_back(std::move(e));
             }
@@ -303,6 +304,22 @@ VALIGN_EXPORT int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode)
         return 1;
     }
     return flat_guard([&] { e->impl->set_ragged_batching(mode); });
+}
+
+VALIGN_EXPORT int valign_hip_host_register(void *ptr, unsigned long long bytes) {
+    return flat_guard([&] { valign::HostRegistry::instance().add(ptr, (size_t)bytes); });
+}
+
+VALIGN_EXPORT int valign_hip_host_unregister(void *ptr) {
+    return flat_guard([&] { valign::HostRegistry::instance().remove(ptr); });
+}
+
+VALIGN_EXPORT int valign_hip_set_host_packing(valign_hip_engine *e, int mode) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_host_packing(mode); });
 }
 
 VALIGN_EXPORT int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb) {

@@ -10,6 +10,7 @@
 // (tests/host_pipeline_check.cpp, `make sanitize`); hip_engine.hip.h includes it unchanged.
 #pragma once
 
+#include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -119,6 +120,64 @@ private:
     std::exception_ptr error_;
 };
 
+// ---- 4-bit base classes for the trip across PCIe (score path) ----
+// score_alignments only ever looks at the CLASS of a base (DefaultKernel.h:43-60: A/a 1, T/t 2, C/c 3, G/g 4, N/n 5,
+// anything else 0), so the host-pointer path may send classes instead of ASCII: two bases per byte, first base in
+// the low nibble, a sequence of `len` bases in (len + 1) / 2 bytes.  The device expands them back to one canonical
+// byte per base (pack_kernels.hip.h) and the score kernels run unchanged -- bit-identical scores, half the H2D bytes.
+// (compute_alignments copies the caller's BYTES into its result rows -- lower case stays lower case -- and keeps ASCII.)
+inline uint8_t base_class_of(uint8_t ch) {
+    switch (ch & 0xDF) {            // fold case; bytes >= 0x80 never match
+        case 'A': return 1;
+        case 'T': return 2;
+        case 'C': return 3;
+        case 'G': return 4;
+        case 'N': return 5;
+        default: return 0;
+    }
+}
+
+inline size_t packed_length(int len) { return ((size_t)len + 1) / 2; }
+
+inline void pack_classes_scalar(const uint8_t *src, int len, uint8_t *dst) {
+    static const struct Table {
+        uint8_t cls[256];
+        Table() { for (int c = 0; c < 256; ++c) cls[c] = base_class_of((uint8_t)c); }
+    } table;
+    int i = 0;
+    for (; i + 1 < len; i += 2) dst[i >> 1] = (uint8_t)(table.cls[src[i]] | (table.cls[src[i + 1]] << 4));
+    if (i < len) dst[i >> 1] = table.cls[src[i]];
+}
+
+// 32 bases -> 16 bytes per step: the class comes from a 16-entry table on the low nibble of the byte, valid only where
+// the byte's high nibble (case bit cleared) is the one that letter has; vpmaddubsw folds byte pairs into nibble pairs
+__attribute__((target("avx2"))) inline void pack_classes_avx2(const uint8_t *src, int len, uint8_t *dst) {
+    const __m256i lo_mask = _mm256_set1_epi8(0x0F);
+    // low nibble: A = x1, C = x3, T = x4, G = x7, N = xE
+    const __m256i cls_of = _mm256_setr_epi8(0, 1, 0, 3, 2, 0, 0, 4, 0, 0, 0, 0, 0, 0, 5, 0, 0, 1, 0, 3, 2, 0, 0, 4, 0, 0, 0, 0, 0, 0, 5, 0);
+    const __m256i hi_of = _mm256_setr_epi8(-1, 4, -1, 4, 5, -1, -1, 4, -1, -1, -1, -1, -1, -1, 4, -1, -1, 4, -1, 4, 5, -1, -1, 4, -1, -1, -1, -1,
+                                           -1, -1, 4, -1);
+    const __m256i fold = _mm256_set1_epi8((char)0xDF), weights = _mm256_set1_epi16(0x1001);
+    int i = 0;
+    for (; i + 32 <= len; i += 32) {
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + i));
+        const __m256i lo = _mm256_and_si256(c, lo_mask);
+        const __m256i hi = _mm256_and_si256(_mm256_srli_epi16(_mm256_and_si256(c, fold), 4), lo_mask);
+        const __m256i ok = _mm256_cmpeq_epi8(hi, _mm256_shuffle_epi8(hi_of, lo));
+        const __m256i cls = _mm256_and_si256(_mm256_shuffle_epi8(cls_of, lo), ok);
+        const __m256i pairs = _mm256_maddubs_epi16(cls, weights);              // 16 x (even + 16 * odd)
+        const __m256i bytes = _mm256_permute4x64_epi64(_mm256_packus_epi16(pairs, pairs), 0x08);
+        _mm_storeu_si128((__m128i *)(dst + (i >> 1)), _mm256_castsi256_si128(bytes));
+    }
+    if (i < len) pack_classes_scalar(src + i, len - i, dst + (i >> 1));
+}
+
+inline void pack_classes(const uint8_t *src, int len, uint8_t *dst) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) pack_classes_avx2(src, len, dst);
+    else pack_classes_scalar(src, len, dst);
+}
+
 // Caller-provided contiguous result buffers (valign_hip_align_host): rows = n * 2 * AL bytes, idx = n * 4 shorts
 struct FlatSink {
     uint8_t *rows;
@@ -156,6 +215,24 @@ public:
             for (long long i = lo; i < hi; ++i) {
                 memcpy(dst_reads + (size_t)i * R, reads[i], (size_t)R);
                 memcpy(dst_refs + (size_t)i * F, refs[i], (size_t)F);
+            }
+        });
+    }
+
+    // the same with 4-bit classes: reads[i] -> dst_reads + i * packed_length(R) ...
+    void gather_packed(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads,
+                       uint8_t *dst_refs, int threads) {
+        const int R = R_, F = F_;
+        const size_t PR = packed_length(R), PF = packed_length(F);
+        for_ranges(threads, cnt, 4096, [=](int, long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                if (i + 4 < hi) {                      // every sequence is a heap block of its own: keep misses in flight
+                    __builtin_prefetch(reads[i + 4]);
+                    __builtin_prefetch(refs[i + 4]);
+                    __builtin_prefetch(refs[i + 4] + 64);
+                }
+                pack_classes((const uint8_t *)reads[i], R, dst_reads + (size_t)i * PR);
+                pack_classes((const uint8_t *)refs[i], F, dst_refs + (size_t)i * PF);
             }
         });
     }

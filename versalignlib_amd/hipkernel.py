@@ -62,6 +62,9 @@ def lib():
         L.valign_hip_set_traceback_policy.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_band_width.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_pointer_scratch_cap_mb.argtypes = [vp, ctypes.c_longlong]
+        L.valign_hip_set_host_packing.argtypes = [vp, ctypes.c_int]
+        L.valign_hip_host_register.argtypes = [vp, ctypes.c_ulonglong]
+        L.valign_hip_host_unregister.argtypes = [vp]
         L.valign_hip_set_score_width.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_ragged_batching.argtypes = [vp, ctypes.c_int]
         L.valign_hip_score_device.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, vp, vp, vp]
@@ -78,13 +81,25 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_host_packing", "valign_hip_host_register", "valign_hip_host_unregister", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
 
 def _err():
     return lib().valign_hip_last_error().decode(errors="replace")
+
+
+def host_register(array):
+    """Page-lock a numpy array for the device (valign_hip_host_register): result buffers registered once take the
+    device's copies directly in Engine.align_host(out=...).  Unregister before the array is freed."""
+    if lib().valign_hip_host_register(array.ctypes.data, array.nbytes) != 0:
+        raise HipKernelError(_err())
+
+
+def host_unregister(array):
+    if lib().valign_hip_host_unregister(array.ctypes.data) != 0:
+        raise HipKernelError(_err())
 
 
 class Engine:
@@ -110,6 +125,11 @@ class Engine:
     def set_pointer_scratch_cap_mb(self, mb):
         """Cap of compute_alignments' device-side pointer scratch in MiB (0: 64 GiB / half the free HBM)."""
         if lib().valign_hip_set_pointer_scratch_cap_mb(self._h, int(mb)) != 0:
+            raise HipKernelError(_err())
+
+    def set_host_packing(self, mode):
+        """Host-pointer score path: 1 = 4-bit base classes across PCIe (default), 0 = raw ASCII."""
+        if lib().valign_hip_set_host_packing(self._h, int(mode)) != 0:
             raise HipKernelError(_err())
 
     def set_score_width(self, bits):
