@@ -125,8 +125,11 @@ def pmc_profile(kernel_key, pairs):
                 prof = json.load(f)
             if prof.get("csrc_sha16") != want or int(prof["pairs"]) != int(pairs):
                 continue
-            return prof["kernels"][kernel_key], os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError, TypeError):
+            kernels = prof["kernels"]
+            if kernel_key not in kernels:           # (a trailing template argument chosen at run time: first match by prefix)
+                kernel_key = next(k for k in kernels if k.startswith(kernel_key.rstrip(">")))
+            return kernels[kernel_key], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError, StopIteration):
             continue
     return None, None
 
@@ -274,6 +277,9 @@ def host_cores():
     return host_cpus()["effective"]
 
 
+BAND_BLOCK = [160, 4]       # (block rows, column alignment) of the band the engine computes: set from its describe()
+
+
 def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
     """Oracle on the host cores over a bounded sample of the same batch (rank 0, N == 1): threads = the CPUs this
     process really has (host_cpus).  Returns (record, oracle scores of the sample) -- the scores are what the timed
@@ -286,7 +292,7 @@ def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
 
     def run(h_reads, h_refs):
         if band:
-            return cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=cores, block_rows=160, col_align=4)   # VALIGN_HIP_BAND_*: the same cells as the GPU
+            return cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=cores, block_rows=BAND_BLOCK[0], col_align=BAND_BLOCK[1])   # the same cells as the GPU
         return cpu_ref.score(0, h_reads, h_refs, sc, threads=cores, affine=affine)
 
     probe = max(1, (512 * cores * 75000) // (R * F)) if not band else cores
@@ -321,7 +327,7 @@ def verify_scores(device_scores, reads, refs, affine, R=R, F=F, band=0, oracle_s
         h_reads, h_refs = reads[:m].cpu().numpy(), refs[:m].cpu().numpy()
         th = max(1, min(cpu_ref.max_threads(), host_cores()))
         if band:
-            oracle_scores = cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=th, block_rows=160, col_align=4)
+            oracle_scores = cpu_ref.score_banded_sw(h_reads, h_refs, band, sc, threads=th, block_rows=BAND_BLOCK[0], col_align=BAND_BLOCK[1])
         else:
             oracle_scores = cpu_ref.score(0, h_reads, h_refs, sc, threads=th, affine=affine)
     m = len(oracle_scores)
@@ -617,6 +623,8 @@ def main(argv=None):
         eng = hipkernel.Engine(RR, FF, lin_sc, device=local_rank)
         eng.set_band_width(LONG_BAND)
         eng.set_score_width(32)
+        dd = eng.describe(0, n)
+        BAND_BLOCK[:] = [dd["band_block_rows"], dd["band_col_align"]]
     else:
         # `value` is the int16-cell kernel BASELINE.json names; the half-float-cell kernel the engine would
         # pick by itself for this scoring is reported beside it (half_float)
@@ -661,8 +669,9 @@ def main(argv=None):
         d = eng.describe(0, n)
         cells = d.get("score_cells", "int16")
         if long_mode:
-            kernel_name = "score_long_kernel<16,10,SW,shared-gap,int32>"
-            pmc_key = "score_long_kernel<16, 10, 0, true, true, false>"
+            chain = d.get("band_block_rows") == 16
+            kernel_name = "score_band_kernel<16,shared-gap> (cyclic block chain, int32 cells)" if chain else "score_long_kernel<16,10,SW,shared-gap,int32>"
+            pmc_key = "score_band_kernel<16, true>" if chain else "score_long_kernel<16, 10, 0, true, true, false>"
             workload = ("%d pairs/GPU, 10 kbp x 10 kbp, SW linear-gap banded (%d diagonals), int32 cells, inputs resident in HBM%s"
                         % (n, LONG_BAND, ", RCCL all-gather of scores" if world > 1 else ""))
             metric = "GCUPS (giga DP cell updates/sec, full-matrix cells) SW banded, 10 kbp x 10 kbp"

@@ -31,9 +31,18 @@ def ref_kernel(name):
     return path if os.path.exists(path) else None
 
 
-def band_constants():
-    """(block_rows, col_align) of libHIPKernel.so's documented band, read from include/valign_hip.h."""
+def band_constants(R=None, F=None, band=0, scoring=None):
+    """(block_rows, col_align) of the band libHIPKernel.so computes for this shape / band / scoring, as the library
+    itself reports them (valign_hip_describe: "band_block_rows", "band_col_align"; include/valign_hip.h documents
+    which block shape applies where).  Needs the GPU library; without a shape: the header's strip constants."""
     import re
-    text = open(os.path.join(ROOT, "include", "valign_hip.h")).read()
-    return (int(re.search(r"#define\s+VALIGN_HIP_BAND_BLOCK_ROWS\s+(\d+)", text).group(1)),
-            int(re.search(r"#define\s+VALIGN_HIP_BAND_COL_ALIGN\s+(\d+)", text).group(1)))
+    if R is None:
+        text = open(os.path.join(ROOT, "include", "valign_hip.h")).read()
+        return (int(re.search(r"#define\s+VALIGN_HIP_BAND_BLOCK_ROWS\s+(\d+)", text).group(1)),
+                int(re.search(r"#define\s+VALIGN_HIP_BAND_COL_ALIGN\s+(\d+)", text).group(1)))
+    from versalignlib_amd import hipkernel
+    eng = hipkernel.Engine(R, F, scoring)
+    eng.set_band_width(band)
+    d = eng.describe(0, 1)
+    eng.close()
+    return d["band_block_rows"], d["band_col_align"]

@@ -78,7 +78,7 @@ def test_config5_full_size_per_gpu():
     R = F = 10000
     blk, reps = 32, 1024
     reads, refs = synth.make_pairs(blk, R, F, seed=59, sub_rate=0.1, indel_rate=0.002, n_run_frac=0.2, short_frac=0.1)
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, 512)
     exp = cpu_ref.score_banded_sw(reads, refs, 512, threads=8, block_rows=block_rows, col_align=col_align)
     eng = hipkernel.Engine(R, F)
     eng.set_band_width(512)

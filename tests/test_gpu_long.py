@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import cpu_ref
-from versalignlib_amd import build, host, synth
+from versalignlib_amd import build, hipkernel, host, synth
 
 from conftest import band_constants
 
@@ -64,7 +64,7 @@ def test_banded_smith_waterman(R, F, n, seed, band):
     equality with the oracle's restatement of the block definition; the sandwich
     per-cell band <= result <= unbanded; and a band wider than the matrix is the reference's result."""
     reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.05, short_frac=0.08)
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, band)
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band) as hip:
         got = hip.score_alignments(0, reads, refs)
         assert '"band_width": %d' % band in hip.drain_log()
@@ -92,12 +92,13 @@ def test_band_definitions_differ_where_they_should():
         cut = int(rng.integers(300, 700))
         reads[p, cut + shift:] = refs[p, cut:F - shift]
         reads[p, cut:cut + shift] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=shift)
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, band)
     per_cell = cpu_ref.score_banded_sw(reads, refs, band, threads=8)
     block = cpu_ref.score_banded_sw(reads, refs, band, threads=8, block_rows=block_rows, col_align=col_align)
+    strips = cpu_ref.score_banded_sw(reads, refs, band, threads=8, block_rows=160, col_align=4)      # the strip kernel's blocks
     full = cpu_ref.score(0, reads, refs, threads=8)
-    assert (per_cell <= block).all() and (block <= full).all()
-    assert (per_cell < block).any() and (block < full).any()
+    assert (per_cell <= block).all() and (block <= strips).all() and (strips <= full).all()
+    assert (per_cell < strips).any() and (block < full).any()
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band) as hip:
         assert np.array_equal(hip.score_alignments(0, reads, refs), block)
 
@@ -108,7 +109,7 @@ def test_config5_banded_10k():
     R = F = 10000
     n = 24
     reads, refs = synth.make_pairs(n, R, F, seed=56, sub_rate=0.1, indel_rate=0.0, n_run_frac=0.2, short_frac=0.1)
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, 512)
     exp = cpu_ref.score_banded_sw(reads, refs, 512, threads=8, block_rows=block_rows, col_align=col_align)
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512, score_width=32) as hip:
         got = hip.score_alignments(0, reads, refs)
@@ -116,7 +117,8 @@ def test_config5_banded_10k():
     assert np.array_equal(got, exp)
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=512) as hip:
         assert np.array_equal(hip.score_alignments(0, reads, refs), exp)
-        assert '"score_cells": "int16"' in hip.drain_log()
+        # (linear gaps under a band run on the block chain of band_kernels.hip.h: int32 cells whatever the range needs)
+        assert '"score_cells": "int32"' in hip.drain_log()
     full = cpu_ref.score(0, reads[:4], refs[:4], threads=8)
     assert (got[:4] <= full).all()
     assert (cpu_ref.score_banded_sw(reads[:4], refs[:4], 512, threads=8) <= got[:4]).all()
@@ -130,7 +132,7 @@ def test_config5_cells_that_need_int32():
     reads, refs = synth.make_pairs(n, R, F, seed=58, sub_rate=0.12, indel_rate=0.0, n_run_frac=0.0, short_frac=0.5)
     sc = cpu_ref.Scoring.make(5, -4, -6, -6)
     keys = dict(score_match=5, score_mismatch=-4, score_gap_read=-6, score_gap_ref=-6)
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, 512, hipkernel.Scoring.make(5, -4, -6, -6))
     with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
         got = hip.score_alignments(0, reads, refs)
         assert '"score_cells": "int32"' in hip.drain_log()

@@ -1,0 +1,320 @@
+// band_kernels.hip.h -- banded Smith-Waterman scores of long reads (BASELINE config 5: 10 kbp x 10 kbp, 512
+// diagonals, int32 cells) as a CYCLIC systolic chain.  Same recurrence and results as score_long_kernel
+// (reference semantics: src/Kernels/default/DefaultKernel.cpp:83-138 on the cells of the band), different schedule:
+//
+//   * A lane group is G = 32 lanes; lane l owns ROW BLOCK b = m * G + l (K rows) of "strip" m and sweeps ONLY that
+//     block's own band window [lo_b, hi_b] -- the band of include/valign_hip.h on blocks of K rows -- one column per
+//     step.  score_long_kernel sweeps, per 160-row strip, the rectangle that contains the band of all its rows:
+//     at 512 diagonals a quarter of its lane-steps lie outside the band and every strip pays a pipeline fill.
+//   * Block b starts d steps after block b - 1 (d: the window width divided by G, rounded up, so that a lane is done
+//     with block b when block b + G is due).  The bottom row of block b - 1 reaches block b through an LDS DELAY
+//     RING: every lane writes its last row's cell each step, its successor reads the cell written D_b = d -
+//     (start_b - start_{b-1}) steps earlier -- the same column.  Lane 0 of strip m + 1 follows lane G - 1 of strip m
+//     through the very same ring: the chain is a cycle, NO strip boundary row ever goes to HBM (score_long_kernel:
+//     15 GB per 32,768 pairs for 0.66 GB of sequences) and no lane waits for a strip to drain.
+//   * A lane is "inactive" outside its window (EXEC-masked; it writes 0 into its ring, which is what the band gives
+//     the cells out there) -- blocks of top padding, the warm-up column that fetches the diagonal neighbour of a
+//     block's first cell, and the d * G - width idle steps of a period.
+//   * Every d steps is an EVENT (wave-uniform): block b = t / d starts on lane b % G of both groups.  The event
+//     resets that lane's cells, loads its window, rewrites ITS rows of the query profile in place (all 64 lanes
+//     cooperate; the read bases were requested one event earlier), and tops up the group's reference ring
+//     (requested one event earlier as well).  No barrier anywhere: one wave per block.
+//   * int32 cells (one pair per register: the group's two pairs take turns, as in score_long_kernel) read an int32
+//     query profile -- no sign extension per cell (5.5 -> 4.5 VALU per cell) -- laid out [4 rows][slab][lane] so that
+//     a lane's K scores are K/4 ds_read_b128 at 16-byte lane stride (conflict-free within a slab).
+//
+// tools/band_schedule_model.py states this schedule in plain Python and checks it against the oracle's block band;
+// the constants of the band definition are reported by valign_hip_describe ("band_block_rows", "band_col_align").
+#pragma once
+
+#include "dp_kernels.hip.h"
+
+namespace valign {
+
+constexpr int kBandG = 32;                 // lanes per group: two groups (= two pairs at a time) per wave
+constexpr int kBandGroups = kWave / kBandG;
+constexpr int kBandSlabs = 4 * kBandGroups + 1;                // (class, group) + one all-zero slab (both groups)
+
+struct BandBlock {          // per row block, computed once on the host (Engine::band_plan)
+    int start;              // column of the block's first step (its window's first column - 1: the warm-up column)
+    int lo;                 // first column of the window, clipped to the matrix (0x3FFFFFFF: nothing to compute)
+    int span;               // last column - first column
+    int delay;              // steps between the predecessor's write and this block's read of the same column
+};
+
+struct BandArgs {
+    const uint8_t *reads;
+    const uint8_t *refs;
+    int16_t *scores;
+    const BandBlock *blocks;    // nb + kBandG + 2 entries (the tail: empty blocks)
+    const int *fill_to;         // per event: the reference ring must hold every column below this one
+    long long n;
+    int R, F;
+    int nb;                     // real blocks = strips * kBandG
+    int pad_rows;               // padding rows above the read (class "none")
+    int d;                      // steps between block starts
+    int ring_depth;             // delay ring slots per lane (power of two > every delay)
+    int code_cols;              // reference ring columns per group (power of two)
+    short match, mismatch;
+    short gap_read, gap_ref;
+};
+
+template <int K>
+struct BandLds {
+    static constexpr int kRowChunks = K / 4;
+    static constexpr int kChunkBytes = kBandSlabs * kBandG * 16;          // one 4-row chunk of every slab
+    static constexpr int kProf = 0;
+    static constexpr int kProfBytes = kRowChunks * kChunkBytes;
+    __host__ __device__ static constexpr int codes() { return kProfBytes; }
+    // (the delay rings are addressed as base | offset: aligned to one lane's ring)
+    __host__ __device__ static int ring(int code_cols, int ring_depth) {
+        const int at = kProfBytes + kBandGroups * code_cols, a = ring_depth * 4;
+        return (at + a - 1) / a * a;
+    }
+    // (ring_depth 0: the unit-delay kernel, no ring)
+    __host__ __device__ static int total(int code_cols, int ring_depth) { return ring(code_cols, ring_depth ? ring_depth : 1) + kWave * ring_depth * 4; }
+};
+
+// SYM: gap_read == gap_ref (one saturating subtract per cell serves both neighbours).
+// UNIT: every block reads its predecessor's cell of the step before (delay 1: the window starts advance by d - 1 columns
+// per block, BASELINE config 5's 10 kbp x 10 kbp at 512 diagonals is such a case) -- then the cell travels by DPP
+// (lane 0 <- lane 31, lane 32 <- lane 63 through two scalar registers) and no LDS round trip sits between two steps of the
+// chain.  Otherwise the delay ring, whose reads run one step ahead (the host plans every delay >= 2 for that).
+template <int K, bool SYM, bool UNIT>
+__global__ void __launch_bounds__(64)
+score_band_kernel(const BandArgs args) {
+    static_assert(K % 4 == 0, "rows per lane come in chunks of four");
+    using lay = BandLds<K>;
+    const int lane = threadIdx.x;
+    const int grp = lane / kBandG;
+    const int l = lane % kBandG;
+    const int R = args.R, F = args.F, d = args.d;
+    constexpr int kPairsPerWave = 2 * kBandGroups;
+
+    unsigned char *codes = valign_smem + lay::codes();
+    const unsigned prof_lds = lds_offset(valign_smem);
+    const unsigned ring_lds = lds_offset(valign_smem + lay::ring(args.code_cols, UNIT ? 1 : args.ring_depth));
+    // delay ring, slot-major: slot s of lane x at ring + s * 256 + x * 4 (a step's 64 stores hit 64 banks)
+    const unsigned ring_mask = ((unsigned)args.ring_depth - 1u) * 256u;          // of 256 * slot
+    const unsigned code_mask = (unsigned)args.code_cols - 1u;
+    const unsigned my_ring = ring_lds + (unsigned)lane * 4u;
+    const unsigned pred_ring = ring_lds + (unsigned)(grp * kBandG + ((l + kBandG - 1) % kBandG)) * 4u;
+    const unsigned codes_lds = lds_offset(codes) + (unsigned)grp * (unsigned)args.code_cols;      // aligned to code_cols (<= 2048)
+    // a lane's scores of class slab s: K/4 chunks of 16 bytes at prof + chunk * kChunkBytes + (s * G + l) * 16
+    const unsigned lane_prof = prof_lds + (unsigned)l * 16u;
+    constexpr unsigned kSlabStride = kBandG * 16;
+    constexpr unsigned zero_slab = 4 * kBandGroups;                   // (class * kBandGroups + grp for a real class)
+    const unsigned gmag_ref = (unsigned)(-(int)args.gap_ref), gmag_read = (unsigned)(-(int)args.gap_read);
+
+    // the all-zero slabs and the never-filled part of the reference ring, once
+    for (int i = lane; i < lay::kRowChunks * kBandG * 4; i += kWave) {
+        const int chunk = i / (kBandG * 4), rest = i % (kBandG * 4);
+        reinterpret_cast<unsigned *>(valign_smem + chunk * lay::kChunkBytes + zero_slab * kSlabStride)[rest] = 0u;
+    }
+
+  // A launch is as many one-wave blocks as the device runs side by side (the engine asks the occupancy calculator); every
+  // wave takes quads of pairs in turn.  With a block per quad the 32 waves a CU gets for 32,768 pairs went through it in
+  // 4.7 rounds' time instead of 4 (waves of a round do not retire together and CUs are not handed equal shares).
+  for (long long pair0 = (long long)blockIdx.x * kPairsPerWave; pair0 < args.n; pair0 += (long long)gridDim.x * kPairsPerWave) {
+  const int last = (int)((args.n - pair0 < kPairsPerWave ? args.n - pair0 : kPairsPerWave) - 1);
+  // the group's two pairs take turns (int32 cells: one pair per register)
+  for (int half = 0; half < 2; ++half) {
+    int p_local = 2 * grp + half;
+    p_local = p_local > last ? last : p_local;
+    const uint8_t *my_ref = args.refs + (pair0 + p_local) * F;
+
+    for (int i = lane; i < kBandGroups * args.code_cols; i += kWave) codes[i] = (unsigned char)zero_slab;
+    if (!UNIT)
+        for (int i = lane; i < kWave * args.ring_depth; i += kWave)
+            reinterpret_cast<unsigned *>(valign_smem + lay::ring(args.code_cols, args.ring_depth))[i] = 0u;
+
+    int Hl[K], Gl[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+    int up0 = 0, up_in = 0, best = 0;      // up_in: the predecessor's cell for the coming step (read one step ahead)
+    int j = -0x20000000, lo = 0x3FFFFFFF, span = 0;
+    unsigned rd4 = 0;                      // 256 * (t + 1 - delay): the predecessor's slot of the column this lane reaches NEXT step
+    unsigned t4 = 0;                       // 256 * t
+
+    // ---- what the events prefetch ----
+    // Read bases of the NEXT block's rows: this lane rewrites the profile entry (row my_q, class my_c) of group 0 and
+    // of group 1 -- 64 lanes x 2 = 16 rows x 4 classes x 2 groups.
+    static_assert(K == 16, "the cooperative profile rewrite below maps 64 lanes onto 16 rows x 4 classes");
+    const int my_q = (lane >> 2) & (K - 1), my_c = lane & 3;
+    const unsigned my_letter = (0x47435441u >> (8 * my_c)) & 0xFFu;          // 'A', 'T', 'C', 'G': classes 0..3
+    const int pg0 = (half > last) ? last : half, pg1 = (2 + half > last) ? last : 2 + half;
+    const uint8_t *rows0 = args.reads + (pair0 + pg0) * R - args.pad_rows + my_q;     // + b * K: row my_q of block b
+    const uint8_t *rows1 = args.reads + (pair0 + pg1) * R - args.pad_rows + my_q;
+    const int row_first = args.pad_rows - my_q;                                 // b * K must lie in [row_first, row_first + R)
+    auto row_base = [&](const uint8_t *rows, int b) __attribute__((always_inline)) -> unsigned {
+        const int at = b * K;
+        return (b < args.nb && (unsigned)(at - row_first) < (unsigned)R) ? (unsigned)rows[at] : 0u;
+    };
+    // substitution score of a read base against this lane's class: 0 unless both are one of ACGT
+    auto entry_score = [&](unsigned ch) __attribute__((always_inline)) -> int {
+        const unsigned u = ch & 0xDFu, t = u - 'A';                              // bytes >= 0x80 keep bit 7: never a letter
+        const bool valid = t < 20u && ((0x80045u >> t) & 1u);                    // A, C, G, T
+        return u == my_letter ? (int)args.match : (valid ? (int)args.mismatch : 0);
+    };
+    // reference bases for the ring: lane -> column first + lane % 32 (+ 32 in the second round) of its group's pair;
+    // the ring holds the slab of the lane-independent part of the profile address: class * groups + group, or the zero slab
+    const uint8_t *refl = my_ref + l;
+    auto ref_base = [&](int first) __attribute__((always_inline)) -> unsigned {
+        return first + l < F ? (unsigned)refl[first] : 0u;
+    };
+    auto slab_of = [&](unsigned ch) __attribute__((always_inline)) -> unsigned {
+        const unsigned u = ch & 0xDFu, t = u - 'A';
+        const bool valid = t < 20u && ((0x80045u >> t) & 1u);
+        // A (t = 0) -> 0, T (19) -> 1, C (2) -> 2, G (6) -> 3
+        const unsigned cls = t == 0u ? 0u : (t == 19u ? 1u : (t == 2u ? 2u : 3u));
+        return valid ? cls * kBandGroups + (unsigned)grp : zero_slab;
+    };
+    auto commit_codes = [&](int first, int limit, unsigned b0, unsigned b1) __attribute__((always_inline)) {
+        const int c0 = first + l, c1 = first + kBandG + l;
+        if (c0 < limit) codes[grp * args.code_cols + (c0 & code_mask)] = (unsigned char)slab_of(b0);
+        if (c1 < limit) codes[grp * args.code_cols + (c1 & code_mask)] = (unsigned char)slab_of(b1);
+    };
+
+    // before the first event: the ring up to fill_to[0] (synchronously, once), block 0's read bases
+    int filled = 0;
+    for (; filled < args.fill_to[0]; filled += 2 * kBandG)
+        commit_codes(filled, args.fill_to[0], ref_base(filled), ref_base(filled + kBandG));
+    filled = args.fill_to[0];
+    unsigned pre_row0 = row_base(rows0, 0), pre_row1 = row_base(rows1, 0);
+    unsigned pre_ref0 = 0, pre_ref1 = 0;
+    int pre_first = filled, pre_limit = filled;
+
+    int S0[K], S1[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) S0[q] = S1[q] = 0;
+    unsigned code_next = zero_slab;
+    auto load_scores = [&](unsigned slab, int (&S)[K]) __attribute__((always_inline)) {
+        const unsigned addr = lane_prof + slab * kSlabStride;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const u32x4 v = *(lds_cu32x4 *)(addr + c * lay::kChunkBytes);
+            S[4 * c] = (int)v.x; S[4 * c + 1] = (int)v.y; S[4 * c + 2] = (int)v.z; S[4 * c + 3] = (int)v.w;
+        }
+    };
+
+    // one step: every lane moves one column on.  `S` holds this step's scores, the loads of the next step's go to Snext.
+    auto step = [&](int (&S)[K], int (&Snext)[K]) __attribute__((always_inline)) {
+        const int diag0 = up0;
+        up0 = up_in;                                                     // the cell above this block's first row
+        if (!UNIT) up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));      // ... of the next step (written >= 1 step ago)
+        load_scores(code_next, Snext);                                   // step t + 1
+        code_next = *(lds_cu8 *)(codes_lds | ((unsigned)(j + 2) & code_mask));   // step t + 2
+        int h_out = 0;
+        if ((unsigned)(j - lo) <= (unsigned)span) {
+            int h = up0;
+            int up_c = (int)__builtin_elementwise_sub_sat((unsigned)up0, gmag_ref);
+            int d_cur = diag0 + S[0], d_prev = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                int d_next = 0;
+                if (q + 1 < K) d_next = Hl[q] + S[q + 1];                // before Hl[q] is overwritten
+                int left_c = Gl[q];
+                if (!SYM) left_c = (int)__builtin_elementwise_sub_sat((unsigned)Hl[q], gmag_read);
+                int m = d_cur > left_c ? d_cur : left_c;
+                m = m > up_c ? m : up_c;
+                h = m;
+                Hl[q] = m;
+                up_c = (int)__builtin_elementwise_sub_sat((unsigned)m, gmag_ref);
+                if (SYM) Gl[q] = up_c;
+                if (q & 1) {
+                    int b2 = best > d_prev ? best : d_prev;
+                    best = b2 > d_cur ? b2 : d_cur;
+                } else if (q == K - 1) {
+                    best = best > d_cur ? best : d_cur;
+                }
+                d_prev = d_cur;
+                d_cur = d_next;
+            }
+            h_out = h;
+        }
+        if (UNIT) {
+            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window)
+            const unsigned s31 = (unsigned)__builtin_amdgcn_readlane(h_out, 31), s63 = (unsigned)__builtin_amdgcn_readlane(h_out, 63);
+            int v = __builtin_amdgcn_update_dpp(0, h_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            v = lane == 0 ? (int)s31 : v;
+            up_in = lane == 32 ? (int)s63 : v;
+        } else {
+            *(__attribute__((address_space(3))) unsigned *)(my_ring + (t4 & ring_mask)) = (unsigned)h_out;
+            rd4 += 256;
+            t4 += 256;
+        }
+        ++j;
+    };
+
+    // ================= event: block b starts on lane b % G of both groups =================
+    // The switching lane's first step is its warm-up column (inactive: the scores in flight for it may be anything);
+    // what must be right is the slab of the step after, read here.  Nobody else's pipeline is touched.
+    int b = 0;
+    auto event = [&]() __attribute__((always_inline)) {
+        const int ls = b % kBandG;
+        const BandBlock blk = args.blocks[b];                             // (uniform: scalar loads)
+        commit_codes(pre_first, pre_limit, pre_ref0, pre_ref1);           // (first: the new block's columns may be among them)
+        filled = pre_limit > filled ? pre_limit : filled;
+        if (l == ls) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+            up0 = 0;
+            j = blk.start;
+            lo = blk.lo;
+            span = blk.span;
+            code_next = *(lds_cu8 *)(codes_lds | ((unsigned)(blk.start + 1) & code_mask));
+            if (!UNIT) {
+                // this step's cell from above now, the read for the next step follows in the step itself
+                up_in = (int)*(lds_cu32 *)(pred_ring + ((t4 - 256u * (unsigned)blk.delay) & ring_mask));
+                rd4 = t4 + 256u - 256u * (unsigned)blk.delay;
+            }
+        }
+        // this lane's entries of lane ls's profile rows (bases requested at the previous event)
+        {
+            const unsigned at = ((unsigned)my_q >> 2) * lay::kChunkBytes + (unsigned)ls * 16u + ((unsigned)my_q & 3u) * 4u +
+                                (unsigned)my_c * (kBandGroups * kSlabStride);
+            *reinterpret_cast<int *>(valign_smem + at) = entry_score(pre_row0);
+            *reinterpret_cast<int *>(valign_smem + at + kSlabStride) = entry_score(pre_row1);
+        }
+        // requests for the next event (their latency hides behind the d steps in between)
+        ++b;
+        pre_row0 = row_base(rows0, b);
+        pre_row1 = row_base(rows1, b);
+        pre_first = filled;
+        pre_limit = args.fill_to[b];
+        pre_ref0 = ref_base(pre_first);
+        pre_ref1 = ref_base(pre_first + kBandG);
+    };
+
+    // the last blocks need a full period to finish; two steps per trip (the score registers swap roles), the event
+    // due before either of them
+    const int total_steps = (args.nb + kBandG) * d;
+    int next_event = 0;
+    for (int t = 0; t < total_steps; t += 2) {
+        if (t == next_event) {
+            event();
+            next_event += d;
+        }
+        step(S0, S1);
+        if (t + 1 == next_event) {
+            event();
+            next_event += d;
+        }
+        step(S1, S0);
+    }
+
+    int res = best;
+#pragma unroll
+    for (int dd = kBandG / 2; dd >= 1; dd >>= 1) {
+        const int other = __shfl_xor(res, dd, kWave);
+        res = other > res ? other : res;
+    }
+    if (l == 0) {
+        const long long pa = pair0 + 2 * grp + half;
+        if (pa < args.n) args.scores[pa] = (int16_t)(res > 32767 ? 32767 : res);     // the ABI's score is a short
+    }
+  }
+  }
+}
+
+}  // namespace valign

@@ -26,6 +26,7 @@
 
 #include "host_pipeline.h"
 #include "kernel_instances.hip.h"
+#include "band_kernels.hip.h"
 #include "long_kernels.hip.h"
 #include "pack_kernels.hip.h"
 #include "strip_kernels.hip.h"
@@ -349,6 +350,7 @@ public:
         hipDeviceProp_t prop;
         hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
         arch_ = prop.gcnArchName;
+        cu_count_ = prop.multiProcessorCount;
         if (arch_.find("gfx950") == std::string::npos)
             throw std::runtime_error("device is " + arch_ + "; this library carries gfx950 code only");
         force_g_ = force_g;
@@ -371,6 +373,8 @@ public:
         release_staging();
         release_trace_scratch();
         if (d_brow_) (void)hipFree(d_brow_);
+        if (d_band_blocks_) (void)hipFree(d_band_blocks_);
+        if (d_band_fill_) (void)hipFree(d_band_fill_);
         for (int s = 0; s < kSlots; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
             if (in_done_[s]) (void)hipEventDestroy(in_done_[s]);
@@ -531,11 +535,165 @@ public:
                   "hipLaunchKernel(unpack_kernel)");
     }
 
+    // ---- banded Smith-Waterman scores, linear gaps: the cyclic block chain of band_kernels.hip.h ----
+    static constexpr int kBandK = 16;              // rows per block = the band definition's block (describe: band_block_rows)
+
+    struct BandPlan {
+        bool usable = false, unit_delay = false;
+        int nb = 0, pad_rows = 0, d = 0, ring_depth = 0, code_cols = 0, events = 0;
+        std::vector<BandBlock> blocks;
+        std::vector<int> fill_to;
+    };
+
+    // Windows, start distance, delays and ring sizes of the block chain for (R, F, band): what tools/band_schedule_model.py
+    // calls plan().  `usable` is false where the chain does not pay or does not fit (then score_long_kernel's strips run).
+    BandPlan make_band_plan() const {
+        BandPlan p;
+        const int R = R_, F = F_, w = band_width_ / 2, G = kBandG, K = kBandK;
+        if (band_width_ <= 0 || R <= 0 || F <= 0) return p;
+        const int rows = G * K;
+        const int strips = std::max(1, (R + rows - 1) / rows);
+        p.pad_rows = strips * rows - R;
+        p.nb = strips * G;
+        p.events = p.nb + G;
+        std::vector<int> start((size_t)p.nb), lo((size_t)p.nb), hi((size_t)p.nb);
+        int first_real = -1;
+        for (int b = 0; b < p.nb; ++b) {
+            int r_lo = b * K - p.pad_rows, r_hi = (b + 1) * K - p.pad_rows - 1;
+            if (r_hi < 0) {                            // a block of padding rows only
+                lo[(size_t)b] = 1;
+                hi[(size_t)b] = 0;
+                continue;
+            }
+            if (first_real < 0) first_real = b;
+            r_lo = std::max(r_lo, 0);
+            r_hi = std::min(r_hi, R - 1);
+            const long long a = (long long)r_lo * F / R - w;
+            start[(size_t)b] = (int)a - 1;             // the warm-up column: the diagonal neighbour of the window's first cell
+            lo[(size_t)b] = (int)std::max<long long>(a, 0);
+            hi[(size_t)b] = (int)std::min<long long>((long long)r_hi * F / R + w, F - 1);
+        }
+        for (int b = 0; b < first_real; ++b) start[(size_t)b] = start[(size_t)first_real];
+        int width = 1, dmax = 0, dmin = 1 << 30;
+        for (int b = 0; b < p.nb; ++b) {
+            width = std::max(width, hi[(size_t)b] - start[(size_t)b] + 1);
+            if (b > first_real) {
+                dmax = std::max(dmax, start[(size_t)b] - start[(size_t)b - 1]);
+                dmin = std::min(dmin, start[(size_t)b] - start[(size_t)b - 1]);
+            }
+        }
+        if (dmin > dmax) dmin = dmax;
+        // A block reads its predecessor up to dmax steps late; by then the predecessor may have begun its next block, but only
+        // with that block's warm-up step, which writes the 0 the band gives that cell: width + dmax - 1 steps per period
+        // suffice -- and a lane finishes its own block first (tools/band_schedule_model.py).
+        p.d = std::max((std::max(width, width + dmax - 1) + G - 1) / G, dmax + 1);
+        // every block one step behind its predecessor on the same column: the cell travels by DPP, no ring (UNIT kernel);
+        // otherwise the ring is read one step ahead, which needs every delay >= 2
+        p.unit_delay = dmin == dmax && p.d == dmax + 1 && !getenv("VALIGN_HIP_BAND_RING");
+        if (!p.unit_delay) p.d = std::max(p.d, dmax + 2);
+        const int delay_max = p.d - dmin;
+        p.ring_depth = 4;
+        while (p.ring_depth < delay_max + 1) p.ring_depth *= 2;
+        p.blocks.assign((size_t)p.events + 2, BandBlock{0, 0x3FFFFFFF, 0, 1});
+        for (int b = 0; b < p.nb; ++b) {
+            BandBlock &k = p.blocks[(size_t)b];
+            k.start = start[(size_t)b];
+            if (lo[(size_t)b] <= hi[(size_t)b]) {
+                k.lo = lo[(size_t)b];
+                k.span = hi[(size_t)b] - lo[(size_t)b];
+            }
+            // (blocks of padding write zeros whatever they are asked: their successor may read any slot)
+            k.delay = b > first_real ? p.d - (start[(size_t)b] - start[(size_t)b - 1]) : 2;
+        }
+        // reference ring: by event e every column below fill_to[e] is in the ring -- what any running block reaches in the d
+        // steps after the event plus the sweep's look-ahead of two; the ring must span from the newest block's column to there
+        p.fill_to.assign((size_t)p.events + 2, 0);
+        int reach = 0, span = 0;
+        for (int e = 0; e <= p.events + 1; ++e) {
+            int head = -(1 << 30), tail = 1 << 30;
+            for (int b = std::max(0, e - G + 1); b <= std::min(e, p.nb - 1); ++b) {
+                head = std::max(head, start[(size_t)b] + (e - b) * p.d);
+                tail = std::min(tail, start[(size_t)b] + (e - b) * p.d);
+            }
+            if (head > -(1 << 30)) reach = std::max(reach, std::min(head + p.d + 3, F));
+            p.fill_to[(size_t)e] = reach;
+            if (tail < (1 << 30)) span = std::max(span, reach + 2 * G - std::max(tail, 0));     // (+ what one event may commit early)
+            if (e > 0 && p.fill_to[(size_t)e] - p.fill_to[(size_t)e - 1] > 2 * G) return p;      // more than two rounds per event: not built
+        }
+        p.code_cols = 128;
+        while (p.code_cols < span + 8) p.code_cols *= 2;
+        // What the chain buys is the lane-steps outside the band; it pays while windows are narrow against a strip's slope.
+        // Limits of the kernel: ring addressing (base | offset) and one CU's LDS.
+        if (p.code_cols > 2048 || p.ring_depth > 64) return p;
+        if (p.unit_delay) p.ring_depth = 0;
+        if (BandLds<kBandK>::total(p.code_cols, p.ring_depth) > 40 * 1024) return p;
+        p.usable = true;
+        return p;
+    }
+
+    // score_alignments(SW, linear gaps, band_width > 0) on the block chain; false: not applicable here (strips run instead)
+    bool score_band_device(long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores, hipStream_t stream) {
+        if (no_band_chain_ || sc_.affine || band_width_ <= 0) return false;
+        if (band_plan_width_ != band_width_) {
+            band_plan_ = make_band_plan();
+            band_plan_width_ = band_width_;
+            hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if (d_band_blocks_) (void)hipFree(d_band_blocks_);
+            if (d_band_fill_) (void)hipFree(d_band_fill_);
+            d_band_blocks_ = nullptr;
+            d_band_fill_ = nullptr;
+            if (band_plan_.usable) {
+                hip_check(hipMalloc((void **)&d_band_blocks_, band_plan_.blocks.size() * sizeof(BandBlock)), "hipMalloc(band blocks)");
+                hip_check(hipMalloc((void **)&d_band_fill_, band_plan_.fill_to.size() * sizeof(int)), "hipMalloc(band fill)");
+                hip_check(hipMemcpy(d_band_blocks_, band_plan_.blocks.data(), band_plan_.blocks.size() * sizeof(BandBlock), hipMemcpyHostToDevice), "hipMemcpy");
+                hip_check(hipMemcpy(d_band_fill_, band_plan_.fill_to.data(), band_plan_.fill_to.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+            }
+        }
+        if (!band_plan_.usable) return false;
+        const BandPlan &p = band_plan_;
+        BandArgs a;
+        a.reads = d_reads;
+        a.refs = d_refs;
+        a.scores = d_scores;
+        a.blocks = d_band_blocks_;
+        a.fill_to = d_band_fill_;
+        a.n = n;
+        a.R = R_;
+        a.F = F_;
+        a.nb = p.nb;
+        a.pad_rows = p.pad_rows;
+        a.d = p.d;
+        a.ring_depth = p.ring_depth;
+        a.code_cols = p.code_cols;
+        a.match = (short)sc_.match;
+        a.mismatch = (short)sc_.mismatch;
+        a.gap_read = (short)sc_.gap_read;
+        a.gap_ref = (short)sc_.gap_ref;
+        const bool sym = sc_.gap_read == sc_.gap_ref && !no_sym_;
+        const void *fn = p.unit_delay ? (sym ? (const void *)&score_band_kernel<kBandK, true, true> : (const void *)&score_band_kernel<kBandK, false, true>)
+                                      : (sym ? (const void *)&score_band_kernel<kBandK, true, false> : (const void *)&score_band_kernel<kBandK, false, false>);
+        const int lds = BandLds<kBandK>::total(p.code_cols, p.ring_depth);
+        // as many one-wave blocks as run side by side; each takes quads of pairs in turn (band_kernels.hip.h)
+        int per_cu = 0;
+        hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, (size_t)lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        const long long resident = (long long)std::max(per_cu, 1) * std::max(cu_count_, 1);
+        const long long blocks = no_band_persist_ ? (n + 3) / 4 : std::min<long long>((n + 3) / 4, resident);
+        if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
+        void *kargs[] = {&a};
+        hip_check(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kWave), kargs, (size_t)lds, stream), "hipLaunchKernel(score_band_kernel)");
+        return true;
+    }
+    bool band_chain_in_use() const {
+        return !no_band_chain_ && !sc_.affine && band_width_ > 0 && (band_plan_width_ == band_width_ ? band_plan_.usable : make_band_plan().usable);
+    }
+
     // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
     void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
                            hipStream_t stream, bool wide) {
         if (band_width_ > 0 && alg != kAlgSW)
             throw std::runtime_error("band_width applies to Smith-Waterman scores only");
+        // linear gaps, banded: the cyclic block chain (int32 cells whatever score_width says: same results in the int16 range)
+        if (band_width_ > 0 && alg == kAlgSW && score_band_device(n, d_reads, d_refs, d_scores, stream)) return;
         const int rows = kLongG * kLongK;
         const int ppw = 2 * (kWave / kLongG);
         LongArgs a;
@@ -619,6 +777,7 @@ public:
     // what score_alignments computes in for this mode at the engine's full shape
     const char *score_cell_format(int alg) const {
         if (alg > 1) return "none";
+        if (alg == kAlgSW && band_chain_in_use()) return "int32";
         if (score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg))) return "int32";
         if (!plan_.long_mode && sc_.affine && !no_f16_ && half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K)) return "f16";
         if (!plan_.long_mode && !sc_.affine && ((sc_.gap_read == sc_.gap_ref && !no_sym_) || alg == kAlgNW) && !no_f16_ &&
@@ -1358,19 +1517,21 @@ public:
 
     std::string describe(int opt, long long n) const {
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        char buf[1024];
+        char buf[1400];
         snprintf(buf, sizeof buf,
                  "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
                  "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"band_block_rows\": %d, \"band_col_align\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
                  plan_.long_mode ? 1 : 0, band_width_, ragged_, host_stats_.launches,
                  host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
-                 score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.packed, host_stats_.direct_out, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+                 score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.packed, host_stats_.direct_out,
+                 ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? kBandK : VALIGN_HIP_BAND_BLOCK_ROWS,
+                 ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? 1 : VALIGN_HIP_BAND_COL_ALIGN, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
                  host_stats_.drain_ms);
         return buf;
     }
@@ -1898,6 +2059,13 @@ private:
     bool pack_ = getenv("VALIGN_HIP_NO_PACK") == nullptr;                // host_packing (tuning switch: ASCII across PCIe)
     int16_t *d_scores_[kSlots] = {};
     // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
+    BandPlan band_plan_;               // banded linear SW: the block chain's plan for band_plan_width_, its tables on the device
+    int band_plan_width_ = -1;
+    BandBlock *d_band_blocks_ = nullptr;
+    int *d_band_fill_ = nullptr;
+    int cu_count_ = 0;
+    bool no_band_persist_ = getenv("VALIGN_HIP_BAND_BLOCK_PER_QUAD") != nullptr;   // tuning switch: one block per four pairs
+    bool no_band_chain_ = getenv("VALIGN_HIP_NO_BAND_CHAIN") != nullptr;      // tuning switch: banded scores on score_long_kernel's strips
     unsigned *d_brow_ = nullptr;       // long-read path: strip boundary rows
     size_t brow_bytes_ = 0;
     unsigned *d_ptr_ = nullptr;
