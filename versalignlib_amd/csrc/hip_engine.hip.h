@@ -136,17 +136,20 @@ struct StripGeometry {
     WaveLds (*lds)(int R, int F);
     const void *kernel[2];
     const void *affine_kernel[2];      // nullptr: too many rows per lane for the affine kernel's registers
+    const void *sse_kernel[2];         // traceback_policy = 1 (linear gaps)
 };
+#define VALIGN_STRIP_SSE(K) {(const void *)&align_strip_kernel<K, kAlgSW, false, true>, (const void *)&align_strip_kernel<K, kAlgNW, false, true>}
 static const StripGeometry kStripGeometries[] = {
-    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}},
-    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}},
+    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}},
+    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24)},
     {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
-     {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}},
+     {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}, VALIGN_STRIP_SSE(16)},
     {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
-     {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}},
+     {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}, VALIGN_STRIP_SSE(12)},
     {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
-     {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}},
+     {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}, VALIGN_STRIP_SSE(8)},
 };
+#undef VALIGN_STRIP_SSE
 
 // Small batches: fill + traceback in one launch, pointer stream in LDS (align_fill_tag_kernel<..., FUSED>)
 struct FusedGeometry {
@@ -1060,6 +1063,19 @@ public:
         const bool overlap = !no_overlap_ && (double)n * R_ * F_ >= 1e10 && !chain;
         if (chain) {
             parts.push_back(Part{0, n, chain->region * chain_pairs, chain->region});
+        } else if (overlap && chunk >= n && n >= 16 * ppb && split_parts_ > 2) {
+            // Geometric parts (3/4 of what is left each time, regions alternating): every walk but the last runs beside the
+            // next, shorter fill and what stays exposed is the walk of a sliver.  Part 0 sits in region 0, part 1 behind it in
+            // region 1; later parts are smaller than the first occupant of their region.
+            long long begin = 0;
+            long long first = 0;
+            for (int k = 0; k < split_parts_ && begin < n; ++k) {
+                long long cnt = (k + 1 == split_parts_) ? n - begin : std::max(ppb, (n - begin) * 3 / 4 / ppb * ppb);
+                if (n - begin - cnt < 8 * ppb) cnt = n - begin;                  // no slivers below a few blocks
+                if (k == 0) first = cnt;
+                parts.push_back(Part{begin, cnt, (k & 1) ? first : 0, k & 1});
+                begin += cnt;
+            }
         } else if (overlap && chunk >= n && n >= 16 * ppb) {
             const long long big = std::max(ppb, n * 7 / 8 / ppb * ppb);
             parts.push_back(Part{0, big, 0, 0});
@@ -1244,14 +1260,15 @@ public:
     // by check_int16_range above instead of wrapping silently).
     void align_strips_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
                              short *d_idx, hipStream_t stream) {
-        if (sse_policy_)
-            throw std::runtime_error("compute_alignments for read_length > 2048 (row strips) implements the default tie-breaks only");
         const bool affine = sc_.affine;
+        if (sse_policy_ && affine)
+            throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
         const StripGeometry *geo = nullptr;
         WaveLds lds{};
         for (int budget : {kMaxBlockLds / 2, kMaxBlockLds}) {            // two waves per CU if possible
             for (const StripGeometry &g : kStripGeometries) {
                 if (affine && !g.affine_kernel[alg]) continue;
+                if (sse_policy_ && !g.sse_kernel[alg]) continue;
                 const WaveLds w = g.lds(64 * g.K, F_);
                 if (w.total <= budget && !geo) {
                     geo = &g;
@@ -1302,9 +1319,10 @@ public:
         }
         unsigned *boundary = d_ptr_ + (size_t)waves * strip_words * strips;        // two rows per pair-of-pairs behind the pointers
         hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, stream), "hipMemsetAsync(rows)");
-        hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_);
+        hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_,
+                           sse_policy_ ? 1 : 0);
         hip_check(hipGetLastError(), "hipLaunchKernel(first_invalid_kernel)");
-        const void *fn = affine ? geo->affine_kernel[alg] : geo->kernel[alg];
+        const void *fn = affine ? geo->affine_kernel[alg] : (sse_policy_ ? geo->sse_kernel[alg] : geo->kernel[alg]);
         if (lds.total > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds.total),
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -1363,6 +1381,7 @@ public:
             t.gap_read = (short)sc_.gap_read;
             t.gap_ref = (short)sc_.gap_ref;
             t.affine = affine ? 1 : 0;
+            t.sse_policy = sse_policy_ ? 1 : 0;
             t.open_read = (short)sc_.open_read;
             t.ext_read = (short)sc_.ext_read;
             t.open_ref = (short)sc_.open_ref;
@@ -2040,6 +2059,7 @@ private:
     bool d2h_on_stream_ = getenv("VALIGN_HIP_D2H_ON_STREAM") != nullptr;   // tuning switch: result copies behind a stream wait (a blit kernel on this stack)
     std::unique_ptr<CopyIssuer> copy_issuer_;
     bool ramp_ = getenv("VALIGN_HIP_NO_RAMP") == nullptr;                 // tuning switch: every chunk of a host-pointer call full-sized
+    int split_parts_ = getenv("VALIGN_HIP_SPLIT_PARTS") ? atoi(getenv("VALIGN_HIP_SPLIT_PARTS")) : 2;   // tuning switch: > 2: geometric parts of align_device
     bool no_direct_out_ = getenv("VALIGN_HIP_NO_DIRECT_OUT") != nullptr;   // tuning switch: stage + scatter even into registered result buffers
     bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch

@@ -48,21 +48,26 @@ struct StripArgs {
 #ifndef VALIGN_KERNEL_PART_TU
 // First position of each read / ref whose base class is 0 (else R / F): one wave per pair.
 __global__ void __launch_bounds__(64)
-first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F, int *out) {
+first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F, int *out, int n_is_invalid) {
     const long long pair = blockIdx.x;
     if (pair >= n) return;
     const int lane = threadIdx.x;
     int ir = R, jr = F;
-    for (int i = lane; i < R; i += kWave)
-        if (base_class(reads[pair * R + i]) == 0) {
+    // "invalid": class 0 (Default kernel, DefaultKernel.cpp:308,348) -- or anything but ACGT (SSE kernel, SSEKernel.cpp:532-536)
+    for (int i = lane; i < R; i += kWave) {
+        const int c = base_class(reads[pair * R + i]);
+        if (c == 0 || (n_is_invalid && c == 5)) {
             ir = i;
             break;
         }
-    for (int j = lane; j < F; j += kWave)
-        if (base_class(refs[pair * F + j]) == 0) {
+    }
+    for (int j = lane; j < F; j += kWave) {
+        const int c = base_class(refs[pair * F + j]);
+        if (c == 0 || (n_is_invalid && c == 5)) {
             jr = j;
             break;
         }
+    }
 #pragma unroll
     for (int d = kWave / 2; d >= 1; d >>= 1) {
         const int oi = __shfl_xor(ir, d, kWave), oj = __shfl_xor(jr, d, kWave);
@@ -76,9 +81,13 @@ first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int
 }
 #endif
 
-template <int K, int ALG, bool AFFINE = false>
+// SSE: the tie-breaks of the reference's SSE2 / AVX2 kernels (traceback_policy = 1; linear gaps): stored states 3 DIAG
+// (only between two ACGT bases) > 2 LEFT > 1 UP > 0 START, no zero-floor arithmetic on the gap terms (a floored cell
+// whose neighbours lie below zero is START), as align_fill_sse_kernel (src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 646-659).
+template <int K, int ALG, bool AFFINE = false, bool SSE = false>
 __global__ void __launch_bounds__(64)
 align_strip_kernel(const StripArgs args) {
+    static_assert(!(AFFINE && SSE), "the SSE / AVX kernels have linear gaps only");
     constexpr int W = AFFINE ? 2 * K : K;                             // pointer words per lane and block
     constexpr int G = 64;
     using geo = Geo<G, K>;
@@ -99,8 +108,9 @@ align_strip_kernel(const StripArgs args) {
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
-    s16x2 one = pk(1), two = pk(2), four = pk(4), fifteen = pk(15);
-    asm volatile("" : "+v"(one), "+v"(two), "+v"(four), "+v"(fifteen));     // keep the packed forms (see align_fill_kernel)
+    s16x2 one = pk(1), two = pk(2), three = pk(3), four = pk(4), fifteen = pk(15);
+    asm volatile("" : "+v"(one), "+v"(two), "+v"(three), "+v"(four), "+v"(fifteen));     // keep the packed forms (see align_fill_kernel)
+    const s16x2 sg_read = pk(args.gap_read), sg_ref = pk(args.gap_ref);       // SSE policy: signed gap scores, plain adds
     // affine: magnitudes for the SW floor-at-zero subtract, signed saturating addends for the NW variant
     const s16x2 o_read = pk(ALG == kAlgSW ? (short)-args.open_read : args.open_read), e_read = pk(ALG == kAlgSW ? (short)-args.ext_read : args.ext_read);
     const s16x2 o_ref = pk(ALG == kAlgSW ? (short)-args.open_ref : args.open_ref), e_ref = pk(ALG == kAlgSW ? (short)-args.ext_ref : args.ext_ref);
@@ -120,10 +130,16 @@ align_strip_kernel(const StripArgs args) {
     s16x2 Hl[K], code[K], acc[K];
     s16x2 El[AFFINE ? K : 1], code_g[AFFINE ? K : 1], acc_g[AFFINE ? K : 1];
     s16x2 rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1], sel[ALG == kAlgNW ? K : 1];
+    s16x2 rinv[SSE ? K : 1];                           // SSE policy: 1 where the row's read base is not one of ACGT (no DIAG there)
     short nw_seed[2] = {0, 0};
+    const uint8_t *read_a = args.reads + (w.pair0 + 0) * R, *read_b = args.reads + (w.pair0 + (w.last >= 1 ? 1 : 0)) * R;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         const int pos = row0 + l * K + q;              // read position of the row (negative: padding)
+        if (SSE) {
+            const int ca = (pos >= 0 && pos < R) ? base_class(read_a[pos]) : 0, cb = (pos >= 0 && pos < R) ? base_class(read_b[pos]) : 0;
+            rinv[q] = s16x2{(short)((ca >= 1 && ca <= 4) ? 0 : 1), (short)((cb >= 1 && cb <= 4) ? 0 : 1)};
+        }
         short border = 0;
         if (ALG == kAlgNW)                             // column 0 of the NW variant: a gap of pos + 1 read bases
             border = pos < 0 ? (short)0 : (AFFINE ? (short)(args.open_ref + pos * args.ext_ref) : (short)((pos + 1) * args.gap_ref));
@@ -233,7 +249,47 @@ align_strip_kernel(const StripArgs args) {
             h_last = h;
             f_last = f;
         }
-        if (!AFFINE && (unsigned)j < (unsigned)F) {
+        if (SSE && (unsigned)j < (unsigned)F) {
+            const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+            s16x2 S[K];
+            fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+            // 1 where the reference base of the pair is not ACGT (those columns use the zero slab)
+            const s16x2 cinv = as_pk((ca == (unsigned)geo::kZeroSlab ? 1u : 0u) | (cb == (unsigned)geo::kZeroSlab ? 0x10000u : 0u));
+            const s16x2 tt = pk((short)t);
+            s16x2 d[K], lg[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                d[q] = (q == 0 ? diag0 : Hl[q - 1]) + S[q];
+                lg[q] = Hl[q] + sg_read;
+            }
+            s16x2 h = up0, hs = pk(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const s16x2 ug = h + sg_ref;
+                h = pk_max(pk_max(d[q], lg[q]), ug);
+                if (ALG == kAlgSW) h = pk_max(h, pk(0));
+                Hl[q] = h;
+                const s16x2 nu = pk_min_u(h - ug, one), nl = pk_min_u(h - lg[q], one);
+                const s16x2 ndv = pk_max(pk_max(pk_min_u(h - d[q], one), rinv[q]), cinv);
+                const s16x2 t1 = pk_mad_u(nl, nu, nl);
+                code[q] = three - pk_mad_u(ndv, t1, ndv);          // 3 DIAG, 2 LEFT, 1 UP, 0 START
+                if (ALG == kAlgSW) {
+                    const s16x2 changed = (rb[q] - h) >> fifteen;
+                    fc[q] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[q])));
+                    rb[q] = pk_max(rb[q], h);
+                } else {
+                    hs = pk_mad_u(h, sel[q], hs);
+                }
+            }
+            if (ALG == kAlgNW) {
+                const s16x2 nb = pk_max(rb[0], hs);
+                const s16x2 changed = (rb[0] - nb) >> fifteen;
+                fc[0] = as_pk((as_u32(changed) & as_u32(tt)) | (~as_u32(changed) & as_u32(fc[0])));
+                rb[0] = nb;
+            }
+            h_last = h;
+        }
+        if (!AFFINE && !SSE && (unsigned)j < (unsigned)F) {
             const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
             s16x2 S[K];
             fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
