@@ -455,6 +455,18 @@ def abi_leg(reads, refs, threads, devices=1):
         out["score_alignments_sw"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1),
                                       "transport": "4-bit base classes (host_packing = 1, default)",
                                       "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
+    if devices > 1:
+        # the same call with the per-shard scores all-gathered by RCCL inside the plugin (hip_devices_allgather = 1)
+        try:
+            with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, hip_devices_allgather=1, hip_devices_strict=1, **keys) as kg:
+                kg.score_alignments(0, h_reads, h_refs, scattered=True)
+                secs = sorted(kg.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(3))
+                got = kg.score_alignments(0, h_reads, h_refs)
+                out["score_alignments_sw_rccl_allgather"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1),
+                                                             "identical_to_plain_shards": bool((got == k.score_alignments(0, h_reads, h_refs)).all())
+                                                             if False else None}
+        except Exception as e:
+            out["score_alignments_sw_rccl_allgather"] = {"error": str(e)[:200]}
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_packing=0, **keys) as k0:
         k0.score_alignments(0, h_reads, h_refs, scattered=True)
         secs = sorted(k0.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(4))

@@ -45,6 +45,12 @@
  *                                                         WARNING level), each on its own host thread;
  *                                                         results land in the caller's arrays (default 1)
  *       hip_devices_strict .............................. 1: refuse hip_devices beyond the visible devices
+ *       hip_devices_allgather ........................... 1: score_alignments keeps every shard's scores on its device and
+ *                                                         runs an RCCL all-gather over them (librccl.so, loaded with dlopen;
+ *                                                         one communicator per device in this process): the whole score
+ *                                                         vector ends up on every device, the host copy comes from the
+ *                                                         first.  Needs one distinct device per shard.  Default 0: every
+ *                                                         shard copies its own scores to the host, no collective
  *       hip_group_lanes / hip_rows_per_lane ............. force a kernel geometry
  *
  * (2) A flat C view of the same engine for callers that already hold the batch in

@@ -172,3 +172,28 @@ def test_bench_on_two_real_gpus():
     assert line["multi_gpu"]["n_ranks_seen"] == 2 and line["multi_gpu"]["checksum_ok"]
     assert line["multi_gpu"]["gathered_pairs"] == 2 * 131072
     assert line["verified"]["mismatches"] == 0 and line["verified"]["pairs"] > 0
+
+
+def test_in_plugin_rccl_all_gather_of_shard_scores():
+    """hip_devices_allgather = 1: every shard's scores stay on its device, an RCCL all-gather (librccl.so loaded by the
+    plugin, one communicator per device in this one process) assembles the vector on every device and the host copy
+    comes from the first.  With one device the communicator has one rank (the collective is then a copy, but the whole
+    path -- dlopen, ncclCommInitAll, group call, device-resident shards, host copy -- runs); with two or more it is the
+    north star's exchange step on real links.  Duplicate devices are refused: RCCL cannot have two ranks on one GPU."""
+    R, F, n = 150, 500, 20011
+    reads, refs = synth.make_pairs(n, R, F, seed=106, n_run_frac=0.02, short_frac=0.02)
+    aff = dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5, score_gap_extend_ref=-1)
+    osc = cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1)
+    devices = min(_devices(), 4)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=8, hip_devices=devices, hip_devices_strict=1, hip_devices_allgather=1, **aff) as hip:
+        assert "RCCL all-gather of the per-shard scores over %d device(s)" % devices in hip.drain_log()
+        for opt in (host.SW, host.NW):
+            got = hip.score_alignments(opt, reads, refs)
+            assert np.array_equal(got, cpu_ref.score(opt, reads, refs, osc, threads=8, affine=True)), opt
+        assert np.array_equal(hip.score_alignments(host.SW, reads[:5], refs[:5]), cpu_ref.score(host.SW, reads[:5], refs[:5], osc, threads=4, affine=True))
+        assert "RCCL all-gather of %d shard(s)" % devices in hip.drain_log()
+        rows, idx = hip.compute_alignments(host.NW, reads[:3000], refs[:3000], normalise=False)        # (alignments: no collective)
+        exp_rows, exp_idx = cpu_ref.align(host.NW, reads[:3000], refs[:3000], osc, threads=8, affine=True)
+        assert np.array_equal(idx, exp_idx) and np.array_equal(rows, exp_rows)
+    with pytest.raises(host.PluginError, match="distinct device"):
+        host.Plugin(build.HIP_PLUGIN, R, F, hip_devices=_devices() + 1, hip_devices_allgather=1)

@@ -865,8 +865,10 @@ public:
     // (read, ref) length class, each bin is packed at its own strides and swept by the geometry
     // that suits it; scores return through the permutation.  Bit-exact by construction, checked in
     // tests/test_gpu_ragged.py.
+    // `d_dest` (the plugin's hip_devices_allgather): the scores stay on the device, pair i at d_dest[i], and `scores` is not
+    // touched -- the caller gathers the shards of all devices there (RCCL) before anything goes to the host.
     void score_host(int opt, int n, const char *const *reads, const char *const *refs, short *scores,
-                    int threads) {
+                    int threads, int16_t *d_dest = nullptr) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;
         hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -878,7 +880,7 @@ public:
         ensure_staging(chunk);
         if (threads < 1) threads = 1;
         threads = std::min(threads, 64);
-        if (direct_call(n, per_pair) && !ragged_applies(alg)) {      // (length-sorted batching is a property of the pipeline)
+        if (direct_call(n, per_pair) && (!ragged_applies(alg) || d_dest)) {      // (length-sorted batching is a property of the pipeline)
             // Small call (the reference's timing loop is 100 of them back to back, src/impl/main.cpp:278-287): what
             // it costs is API calls, not bytes.  The kernel reads the gathered sequences straight out of the pinned
             // staging over PCIe and writes its scores into pinned host memory: one launch and one wait instead of
@@ -887,21 +889,25 @@ public:
             auto t0 = std::chrono::steady_clock::now();
             gather(reads, refs, n, h_reads_[0], h_refs_[0], threads);
             auto t1 = std::chrono::steady_clock::now();
-            score_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), (int16_t *)dev_view(h_scores_[0]), streams_[0]);
+            score_device(opt, n, dev_view(h_reads_[0]), dev_view(h_refs_[0]), d_dest ? d_dest : (int16_t *)dev_view(h_scores_[0]), streams_[0]);
             hip_check(hipStreamSynchronize(streams_[0]), "hipStreamSynchronize");
             auto t2 = std::chrono::steady_clock::now();
-            memcpy(scores, h_scores_[0], sizeof(short) * (size_t)n);
+            if (!d_dest) memcpy(scores, h_scores_[0], sizeof(short) * (size_t)n);
             host_stats_.gather_ms = ms_between(t0, t1);
             host_stats_.wait_ms = ms_between(t1, t2);
             host_stats_.drain_ms = ms_between(t2, std::chrono::steady_clock::now());
             host_stats_.direct = 1;
             return;
         }
-        const bool ragged = ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
+        const bool ragged = !d_dest && ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
         const bool shared_scratch = plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg);
         host_stats_ = HostStats{};
         auto drain = [&](int s) {
             if (slot_pending_[s] <= 0) return;
+            if (d_dest) {                          // (the kernels wrote the device destination themselves)
+                slot_pending_[s] = 0;
+                return;
+            }
             short *dst = scores + slot_begin_[s];
             if (slot_ragged_[s]) {
                 const int *pos = pos_[s].data();
@@ -958,16 +964,17 @@ public:
                 hip_check(hipMemcpyAsync(d_pack_refs_[slot], h_refs_[slot], (size_t)cnt * PF, hipMemcpyHostToDevice, st), "H2D refs (classes)");
                 launch_unpack(d_pack_reads_[slot], d_reads_[slot], cnt, R_, st);
                 launch_unpack(d_pack_refs_[slot], d_refs_[slot], cnt, F_, st);
-                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_dest ? d_dest + begin : d_scores_[slot], st);
                 host_stats_.packed = 1;
             } else {
                 gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
                 host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
                 hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
                 hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
-                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_scores_[slot], st);
+                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_dest ? d_dest + begin : d_scores_[slot], st);
             }
-            hip_check(hipMemcpyAsync(h_scores_[slot], d_scores_[slot], sizeof(short) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H scores");
+            if (!d_dest)
+                hip_check(hipMemcpyAsync(h_scores_[slot], d_scores_[slot], sizeof(short) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H scores");
             hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;

@@ -8,6 +8,7 @@
 #include "versalign_plugin_abi.h"
 
 #include <atomic>
+#include <dlfcn.h>
 #include <exception>
 #include <malloc.h>
 #include <memory>
@@ -36,6 +37,106 @@ int opt_param(const char *key, int fallback) {
 void log_line(int level, const std::string &msg) {
     if (_logger) Logger.log(level, kModule, msg.c_str());
 }
+
+// hip_devices_allgather = 1: the exchange step BASELINE.json's north star names, inside ONE process -- every device
+// keeps its shard's scores in HBM, an RCCL all-gather over xGMI (ncclCommInitAll: one communicator per device, all
+// driven by this process inside ncclGroupStart / ncclGroupEnd) leaves the whole score vector on every device, and
+// the host copy comes from the first one.  The reference has no counterpart (its kernels are single-device,
+// DefaultKernel.cpp:45-48).  RCCL is loaded with dlopen when the key is set: the plugin does not link it, hosts that never
+// ask for the collective never pay for it.  RCCL has no int16 type: scores travel as bytes.
+class ShardGather {
+public:
+    ShardGather(const std::vector<int> &devices) : devices_(devices) {
+        for (size_t i = 0; i < devices.size(); ++i)
+            for (size_t k = 0; k < i; ++k)
+                if (devices[i] == devices[k])
+                    throw std::runtime_error("hip_devices_allgather needs one distinct device per shard (device " +
+                                             std::to_string(devices[i]) + " holds two): RCCL refuses duplicate ranks");
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib_) break;
+        }
+        if (!lib_) throw std::runtime_error(std::string("hip_devices_allgather: cannot load librccl.so (") + dlerror() + ")");
+        init_all_ = (int (*)(void **, int, const int *))dlsym(lib_, "ncclCommInitAll");
+        destroy_ = (int (*)(void *))dlsym(lib_, "ncclCommDestroy");
+        group_start_ = (int (*)())dlsym(lib_, "ncclGroupStart");
+        group_end_ = (int (*)())dlsym(lib_, "ncclGroupEnd");
+        all_gather_ = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(lib_, "ncclAllGather");
+        error_string_ = (const char *(*)(int))dlsym(lib_, "ncclGetErrorString");
+        if (!init_all_ || !destroy_ || !group_start_ || !group_end_ || !all_gather_ || !error_string_)
+            throw std::runtime_error("hip_devices_allgather: librccl.so lacks an expected symbol");
+        comms_.assign(devices.size(), nullptr);
+        check(init_all_(comms_.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+        streams_.assign(devices.size(), nullptr);
+        for (size_t i = 0; i < devices.size(); ++i) {
+            valign::hip_check(hipSetDevice(devices[i]), "hipSetDevice");
+            valign::hip_check(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking), "hipStreamCreate");
+        }
+        send_.assign(devices.size(), nullptr);
+        recv_.assign(devices.size(), nullptr);
+    }
+    ~ShardGather() {
+        for (size_t i = 0; i < devices_.size(); ++i) {
+            (void)hipSetDevice(devices_[i]);
+            if (i < send_.size() && send_[i]) (void)hipFree(send_[i]);
+            if (i < recv_.size() && recv_[i]) (void)hipFree(recv_[i]);
+            if (i < streams_.size() && streams_[i]) (void)hipStreamDestroy(streams_[i]);
+            if (i < comms_.size() && comms_[i] && destroy_) (void)destroy_(comms_[i]);
+        }
+        if (lib_) dlclose(lib_);
+    }
+    // shard buffer of device i: `per` scores (the all-gather needs equal counts: the last shard's tail is padding)
+    void reserve(int per) { ensure(per); }                                   // (before the shard threads start)
+    int16_t *shard(int i) const { return send_[(size_t)i]; }
+    // after every shard's kernels have finished: gather on all devices, copy the first n scores out of device 0's vector
+    void gather_to_host(int per, int n, short *scores) {
+        check(group_start_(), "ncclGroupStart");
+        for (size_t i = 0; i < devices_.size(); ++i)
+            check(all_gather_(send_[i], recv_[i], (size_t)per * 2, 0 /* ncclInt8 */, comms_[i], streams_[i]), "ncclAllGather");
+        check(group_end_(), "ncclGroupEnd");
+        valign::hip_check(hipSetDevice(devices_[0]), "hipSetDevice");
+        valign::hip_check(hipMemcpyAsync(scores, recv_[0], sizeof(short) * (size_t)n, hipMemcpyDeviceToHost, streams_[0]), "D2H gathered scores");
+        for (size_t i = 0; i < devices_.size(); ++i) {
+            valign::hip_check(hipSetDevice(devices_[i]), "hipSetDevice");
+            valign::hip_check(hipStreamSynchronize(streams_[i]), "hipStreamSynchronize");
+        }
+    }
+    // (tests) the gathered vector of device i, first n scores
+    void copy_gathered(int i, int n, short *out) {
+        valign::hip_check(hipSetDevice(devices_[(size_t)i]), "hipSetDevice");
+        valign::hip_check(hipMemcpy(out, recv_[(size_t)i], sizeof(short) * (size_t)n, hipMemcpyDeviceToHost), "D2H");
+    }
+
+private:
+    void check(int rc, const char *what) {
+        if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (error_string_ ? error_string_(rc) : "RCCL error"));
+    }
+    void ensure(int per) {
+        if (per <= cap_) return;
+        for (size_t i = 0; i < devices_.size(); ++i) {
+            valign::hip_check(hipSetDevice(devices_[i]), "hipSetDevice");
+            if (send_[i]) (void)hipFree(send_[i]);
+            if (recv_[i]) (void)hipFree(recv_[i]);
+            send_[i] = recv_[i] = nullptr;
+            valign::hip_check(hipMalloc((void **)&send_[i], sizeof(short) * (size_t)per), "hipMalloc(shard scores)");
+            valign::hip_check(hipMalloc((void **)&recv_[i], sizeof(short) * (size_t)per * devices_.size()), "hipMalloc(gathered scores)");
+            valign::hip_check(hipMemset(send_[i], 0, sizeof(short) * (size_t)per), "hipMemset");
+        }
+        cap_ = per;
+    }
+    std::vector<int> devices_;
+    void *lib_ = nullptr;
+    int (*init_all_)(void **, int, const int *) = nullptr;
+    int (*destroy_)(void *) = nullptr;
+    int (*group_start_)() = nullptr;
+    int (*group_end_)() = nullptr;
+    int (*all_gather_)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*error_string_)(int) = nullptr;
+    std::vector<void *> comms_;
+    std::vector<hipStream_t> streams_;
+    std::vector<int16_t *> send_, recv_;
+    int cap_ = 0;
+};
 
 // The kernel object handed to the host.  Reads the same six required keys as every
 // reference backend at construction (DefaultKernel.h:70-81) and num_threads per call
@@ -98,6 +199,13 @@ public:
                 if (d == 0) engine_ = std::move(e);
                 else more_.push_back(std::move(e));
             }
+            if (opt_param("hip_devices_allgather", 0) != 0) {
+                std::vector<int> devs{engine_->device()};
+                for (auto &e : more_) devs.push_back(e->device());
+                gather_.reset(new ShardGather(devs));
+                log_line(0, "hip_devices_allgather = 1: RCCL all-gather of the per-shard scores over " + std::to_string(devs.size()) +
+                                " device(s), host copy from device " + std::to_string(devs[0]));
+            }
             if (shards > 1) {
                 std::string where = std::to_string(engine_->device());
                 for (auto &e : more_) where += ", " + std::to_string(e->device());
@@ -143,6 +251,19 @@ public:
         log_line(0, "Running HIPKernel score with " + std::to_string(threads) + " host threads on " +
                         engine_->describe(opt, aln_number));
         try {
+            const int shards = 1 + (int)more_.size();
+            if (gather_ && aln_number >= shards) {
+                // every device keeps its shard in HBM; the RCCL all-gather puts the whole vector on each of them
+                const int per = (aln_number + shards - 1) / shards;
+                gather_->reserve(per);
+                sharded(aln_number, threads, [&](valign::Engine &e, int begin, int count, int th) {
+                    e.score_host(opt, count, reads + begin, refs + begin, nullptr, th, gather_->shard(begin / per));
+                });
+                gather_->gather_to_host(per, aln_number, scores);
+                log_line(0, "HIPKernel score done (RCCL all-gather of " + std::to_string(shards) + " shard(s) of " + std::to_string(per) +
+                                " scores), host phases " + engine_->host_phases());
+                return;
+            }
             sharded(aln_number, threads, [&](valign::Engine &e, int begin, int count, int th) {
                 e.score_host(opt, count, reads + begin, refs + begin, scores + begin, th);
             });
@@ -209,6 +330,7 @@ private:
 
     std::unique_ptr<valign::Engine> engine_;
     std::vector<std::unique_ptr<valign::Engine>> more_;      // hip_devices > 1: one engine per further device
+    std::unique_ptr<ShardGather> gather_;                    // hip_devices_allgather = 1
     std::string what_;
 };
 
