@@ -23,7 +23,7 @@
  *                                                         many diagonals around the main one (strip band)
  *       score_width ..................................... DP cells of score_alignments: 0 auto (int16,
  *                                                         int32 where int16 could overflow), 16, 32
- *       ragged_batching ................................. length-sorted Smith-Waterman score calls
+ *       ragged_batching ................................. length-sorted score calls, both modes
  *                                                         (trailing non-ACGT padding is not swept,
  *                                                         identical scores): 0 never (default), 1 when a
  *                                                         sample of the call is ragged enough, 2 always
@@ -134,13 +134,14 @@ int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb);
  * Scores beyond the ABI's short saturate at 32767.                                               */
 int valign_hip_set_score_width(valign_hip_engine *e, int bits);
 
-/* Length-sorted batching of valign_hip_score_host / score_alignments for Smith-Waterman: the
+/* Length-sorted batching of valign_hip_score_host / score_alignments (Smith-Waterman and the NW variant): the
  * reference host pads every sequence to the longest (src/util/versalignUtil.cpp:17-33) and every
  * backend sweeps the padding; here pairs are binned by their length without trailing non-ACGT
- * bytes and each bin is swept at its own shape.  Scores are identical (trailing padding cannot
- * raise a Smith-Waterman maximum).  Sorting costs the host one more pass over the sequence tails,
- * so mode 1 (default) only sorts a call whose sampled pairs would skip a third of the cells;
- * 0 = never, 2 = always.                                                                          */
+ * bytes and each bin is swept at its own shape.  Scores are identical: trailing padding scores 0, so it
+ * cannot raise a Smith-Waterman maximum, and every value of the real matrix's last row / column runs
+ * down its diagonal unchanged to the padded matrix's, which is where the NW variant reads its result.
+ * Sorting costs the host one more pass over the sequence tails: 0 = never (default), 1 = when a sample of
+ * the call says a third of the cells would be skipped, 2 = always.                                     */
 int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and

@@ -50,7 +50,7 @@ def test_ragged_scores_match_oracle(small_bins, R, F, n, seed, threads, gaps):
     eng.close()
 
 
-def test_ragged_affine_and_nw_untouched(small_bins):
+def test_ragged_affine_and_nw(small_bins):
     R, F, n = 150, 500, 6000
     reads, refs = synth.make_ragged_pairs(n, R, F, seed=46)
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
@@ -60,10 +60,30 @@ def test_ragged_affine_and_nw_untouched(small_bins):
     got = eng.score_host(host.SW, reads, refs, threads=4)
     assert eng.describe()["ragged_launches"] > 1
     assert np.array_equal(got, cpu_ref.score(host.SW, reads, refs, sc, threads=8, affine=True))
-    # the Needleman-Wunsch variant reads its result off the padded last row / column: never trimmed
+    # the Needleman-Wunsch variant reads its result off the last row / column -- of the trimmed pair just as well: rows and
+    # columns of padding score 0, every boundary value runs down its diagonal unchanged (round 3)
     got = eng.score_host(host.NW, reads, refs, threads=4)
-    assert eng.describe()["ragged_launches"] == 0
+    assert eng.describe()["ragged_launches"] > 1
     assert np.array_equal(got, cpu_ref.score(host.NW, reads, refs, sc, threads=8, affine=True))
+    eng.close()
+
+
+@pytest.mark.parametrize("R,F,n,seed,threads", CASES)
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_ragged_nw_scores_match_oracle(small_bins, R, F, n, seed, threads, gaps):
+    """Length-sorted batches of the NW variant: identical to the padded sweep and to the oracle (N runs, junk bytes
+    and fully padded sequences included), with fewer cells swept."""
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=seed + 100, n_run_frac=0.05, short_frac=0.03, junk_frac=0.03)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    exp = cpu_ref.score(host.NW, reads, refs, sc, threads=8)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, gaps[0], gaps[1]))
+    eng.set_ragged_batching(2)
+    got = eng.score_host(host.NW, reads, refs, threads=threads)
+    info = eng.describe(host.NW, n)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:8]
+    assert info["ragged_launches"] > 1 and info["ragged_cell_fraction"] < (0.75 if R >= 64 else 1.0)
+    eng.set_ragged_batching(0)
+    assert np.array_equal(eng.score_host(host.NW, reads, refs, threads=threads), exp)
     eng.close()
 
 

@@ -121,3 +121,29 @@ def test_sse_policy_oracle_reproduces_the_sse_kernel(path):
         assert np.array_equal(idx, g["sse_idx_" + tag]) and np.array_equal(rows, g["sse_rows_" + tag])
         differs += int((idx != g["idx_" + tag][:n8]).any(axis=1).sum())
     assert differs > 0 or "c2" in path        # the fixtures do exercise the difference to the Default policy
+
+
+def test_nw_variant_score_is_invariant_under_trimming_of_trailing_padding():
+    """What length-sorted NW batches rest on (hip_engine.hip.h: ragged_applies): sweeping a pair at any shape between its
+    trimmed lengths (without trailing non-ACGT bytes) and the padded shape gives the padded shape's NW-variant score --
+    linear and affine, N runs and junk bytes included."""
+    from versalignlib_amd import synth
+    R, F, n = 150, 500, 1500
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=7, n_run_frac=0.05, short_frac=0.05, junk_frac=0.03)
+
+    def trimmed(a):
+        ok = np.isin(a & 0xDF, np.frombuffer(b"ACGT", np.uint8)) & (a < 0x80)
+        return np.where(ok.any(axis=1), a.shape[1] - np.argmax(ok[:, ::-1], axis=1), 0)
+
+    tr, tf = trimmed(reads), trimmed(refs)
+    rng = np.random.default_rng(1)
+    for sc, aff in ((cpu_ref.Scoring.make(), False), (cpu_ref.Scoring.make(2, -1, -2, -4), False),
+                    (cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -4, -2), True)):
+        for opt in (0, 1):
+            full = cpu_ref.score(opt, reads, refs, sc, threads=4, affine=aff)
+            for lo in range(0, n, 300):
+                sl = slice(lo, lo + 300)
+                r2 = max(1, int(min(R, tr[sl].max() + rng.integers(0, 5))))
+                f2 = max(1, int(min(F, tf[sl].max() + rng.integers(0, 9))))
+                part = cpu_ref.score(opt, np.ascontiguousarray(reads[sl, :r2]), np.ascontiguousarray(refs[sl, :f2]), sc, threads=4, affine=aff)
+                assert np.array_equal(part, full[sl]), (opt, aff, lo)

@@ -1842,8 +1842,12 @@ private:
         return std::chrono::duration<double, std::milli>(b - a).count();
     }
 
+    // Both modes (round 3): rows and columns of trailing non-ACGT bytes score 0 against everything, so every value of the
+    // real matrix's last row / last column runs down its diagonal unchanged to the padded matrix's last row / column (gap
+    // moves only lose) -- the NW variant's max(0, last column, last row) of the trimmed pair IS that of the padded pair,
+    // as the Smith-Waterman maximum is.  Checked on the oracle (tests/test_oracle_golden.py) and on the GPU.
     bool ragged_applies(int alg) const {
-        return ragged_ && alg == kAlgSW && !plan_.long_mode && !force_g_ && !force_k_ && score_width_ != 32 &&
+        return ragged_ && alg <= kAlgNW && !plan_.long_mode && !force_g_ && !force_k_ && score_width_ != 32 &&
                R_ > 0 && F_ > 0 && int16_range_ok(alg);
     }
 
