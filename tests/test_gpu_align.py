@@ -384,7 +384,8 @@ def test_pointer_scratch_follows_the_widest_stream_of_an_engine(aff, order):
 
 
 @pytest.mark.parametrize("R,F,n,seed", [(64, 128, 1000, 1), (12, 20, 333, 2), (33, 70, 257, 3), (100, 37, 129, 4), (16, 16, 65, 5),
-                                         (1, 1, 5, 6), (128, 300, 77, 7), (150, 200, 50, 8), (250, 120, 31, 9)])
+                                         (1, 1, 5, 6), (128, 300, 77, 7), (150, 200, 50, 8), (250, 120, 31, 9),
+                                         (150, 500, 1000, 10), (150, 500, 3, 11), (256, 700, 41, 12), (200, 1000, 16, 13)])     # 64 x 4: a wave per pair-of-pairs
 @pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
 def test_fused_small_batch_kernel(monkeypatch, R, F, n, seed, gaps):
     """Small compute_alignments calls run fill + traceback in ONE launch with the pointer stream in LDS

@@ -166,8 +166,11 @@ constexpr FusedGeometry make_fused() {
                           (const void *)&align_fill_tag_kernel<G, K, kAlgNW, false, false, true>}};
 }
 // (32 x 2 / 32 x 4: few rows per lane -- the shortest dependent chain per step, which is what a single-wave call costs)
+// (64 x 4: a whole wave per pair-of-pairs -- the one geometry whose pointer stream fits LDS at 150 x 500, 83 KB: a
+// 1,000-pair compute_alignments call of that shape is ONE launch instead of memset + fill + a traceback that chases
+// pointers through HBM, 600 -> ~200 us)
 static const FusedGeometry kFusedGeometries[] = {make_fused<8, 4>(), make_fused<16, 4>(), make_fused<32, 2>(), make_fused<16, 8>(),
-                                                 make_fused<32, 4>(), make_fused<16, 10>(), make_fused<32, 8>()};
+                                                 make_fused<32, 4>(), make_fused<16, 10>(), make_fused<32, 8>(), make_fused<64, 4>()};
 
 struct LaunchPlan {
     bool long_mode = false;        // sequences too long for one register sweep / LDS-resident reference
