@@ -107,7 +107,9 @@ def launch_ranks(args, argv):
 def source_hash():
     """sha256 over the kernel sources: PMC profiles are only quoted for the sources they were taken from."""
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "versalignlib_amd", "csrc", "*.hip*"))):      # (not the host-only .cpp files)
+    # the device code: every *kernels*.hip.h header and the instantiation lists -- not the engine / plugin (host code that
+    # launches them) and not the host-only .cpp files
+    for path in sorted(glob.glob(os.path.join(ROOT, "versalignlib_amd", "csrc", "*kernel*.hip*"))):
         if os.path.isfile(path):
             h.update(os.path.basename(path).encode())
             h.update(open(path, "rb").read())

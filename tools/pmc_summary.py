@@ -12,7 +12,7 @@ def source_hash():
     """Same stamp as bench.py's: the counters are only quoted for the kernel sources they were taken from."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(root, "versalignlib_amd", "csrc", "*.hip*"))):      # as bench.py: kernel sources only
+    for path in sorted(glob.glob(os.path.join(root, "versalignlib_amd", "csrc", "*kernel*.hip*"))):      # as bench.py: device code only
         if os.path.isfile(path):
             h.update(os.path.basename(path).encode())
             h.update(open(path, "rb").read())

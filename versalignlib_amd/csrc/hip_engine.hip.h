@@ -877,6 +877,7 @@ public:
         hip_check(hipSetDevice(device_), "hipSetDevice");
         const size_t per_pair = (size_t)R_ + F_;
         long long chunk = per_pair ? (long long)(score_chunk_bytes_ / per_pair) : n;
+        chunk = whole_rounds(chunk);
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
         reset_pipeline();
@@ -925,7 +926,7 @@ public:
         // then half a chunk); chunks of many calls deep in the pipeline stay large (fewer launches, full waves).
         long long chunk_no = 0, cnt = 0;
         for (long long begin = 0; begin < n; begin += cnt, slot = (slot + 1) % kSlots, ++chunk_no) {
-            const long long ramp = (ramp_ && n > 2 * chunk) ? (chunk_no == 0 ? chunk / 4 : (chunk_no == 1 ? chunk / 2 : chunk)) : chunk;
+            const long long ramp = (ramp_ && n > 2 * chunk) ? (chunk_no == 0 ? whole_rounds(chunk / 4) : (chunk_no == 1 ? whole_rounds(chunk / 2) : chunk)) : chunk;
             cnt = std::min<long long>(std::max<long long>(ramp, 1024), n - begin);
             auto t0 = std::chrono::steady_clock::now();
             hip_check(hipEventSynchronize(slot_done_[slot]), "hipEventSynchronize");
@@ -1424,6 +1425,7 @@ public:
         const int AL = R_ + F_;
         const size_t per_pair = (size_t)3 * AL + 8;
         long long chunk = per_pair ? (long long)(align_chunk_bytes_ / per_pair) : n;
+        chunk = whole_rounds(chunk);
         chunk = std::max<long long>(chunk, 1024);
         chunk = std::min<long long>(chunk, n);
         reset_pipeline();
@@ -1656,6 +1658,16 @@ private:
         return p;
     }
 
+
+    // A chunk of the host-pointer pipeline is one kernel launch: sized in whole "rounds" of the waves the device runs side by
+    // side (16,384 pairs at 16 x 10: 8 pairs per wave, 8 waves per CU, 256 CUs), it leaves no partly filled last round --
+    // a 48 MB chunk of 150 x 500 was 4.57 rounds and paid for 5.
+    long long whole_rounds(long long pairs) const {
+        if (plan_.long_mode || !plan_.geo || cu_count_ <= 0) return pairs;
+        const long long waves_per_cu = std::min<long long>(32, (kMaxBlockLds / std::max(1, plan_.lds.total * plan_.waves_per_block)) * plan_.waves_per_block);
+        const long long round_pairs = std::max<long long>(1, waves_per_cu) * cu_count_ * plan_.pairs_per_wave;
+        return pairs >= round_pairs ? pairs / round_pairs * round_pairs : pairs;
+    }
 
     // Small calls skip the chunk pipeline (VALIGN_HIP_DIRECT_BYTES: sequence bytes up to which they do; 0 = never)
     bool direct_call(long long n, size_t per_pair) const {
