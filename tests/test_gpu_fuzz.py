@@ -55,9 +55,14 @@ def _scorings(c):
 
 
 @pytest.mark.parametrize("case", range(int(__import__("os").environ.get("VALIGN_FUZZ_CASES", "700"))))
-def test_random_configuration(case):
+def test_random_configuration(case, monkeypatch):
     import torch
     c = _draw(case)
+    if case % 3 == 0:
+        # every third configuration through the chunk pipeline whatever its size: 4-bit classes across PCIe, several
+        # staging slots (round 3); the others take the direct path small calls take by themselves
+        monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")
+        monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(1 << 14))
     R, F, n = c["R"], c["F"], c["n"]
     reads, refs = synth.make_pairs(n, R, F, seed=c["seed"], indel_rate=0.03, n_run_frac=0.05, short_frac=0.1,
                                    lowercase_frac=0.03, junk_frac=0.03)
@@ -86,3 +91,15 @@ def test_random_configuration(case):
         hrows, hidx = eng.align_host(opt, reads, refs, threads=2)
         assert np.array_equal(hidx, eidx) and np.array_equal(hrows, erows), (c, "align_host", opt, eng.describe(opt, n)["direct_call"])
     eng.close()
+    if not affine and case % 2 == 0:
+        # banded Smith-Waterman scores on the cyclic block chain (band_kernels.hip.h) -- or on the strips where the plan
+        # says the chain does not fit: the library reports which block shape it computes
+        r = synth._stream(9000 + case, 2, (2,))
+        band = 2 + int(r[0] % np.uint64(2 * max(R, F)))
+        eng = hipkernel.Engine(R, F, hsc)
+        eng.set_band_width(band)
+        d = eng.describe(host.SW, n)
+        got = eng.score_device(host.SW, d_reads, d_refs).cpu().numpy()
+        eng.close()
+        exp = cpu_ref.score_banded_sw(reads, refs, band, osc, threads=8, block_rows=d["band_block_rows"], col_align=d["band_col_align"])
+        assert np.array_equal(got, exp), (c, "band", band, d["band_block_rows"], np.nonzero(got != exp)[0][:6])
