@@ -267,6 +267,91 @@ int vref_align(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t
     return n;
 }
 
+/* ---- the same fills on int32 cells: what the mathematics says where the reference's shorts would wrap
+ * (NW-variant borders beyond -32768: read_length * gap_ref).  Identical to the int16 fills wherever those do not
+ * overflow; libHIPKernel.so takes int32 cells for such alignments instead of refusing them (round 3).           */
+static void nw_fill_wide(const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                         int gr, int gf, int32_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
+    int32_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int32_t) * 2 * (size_t)(F + 1));
+    int last_read = R - 1, last_ref = F - 1;
+    int32_t row_best = INT32_MIN;
+    int row_arg = 0, snap_arg = -1;
+    for (int i = 0; i < R; ++i) {
+        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
+        prow[0] = PTR_UP;
+        cur[0] = (i + 1) * gf;
+        if (last_read == R - 1 && g_class[read[i]] == 0) last_read = i - 1;
+        if (last_read + 1 == i) snap_arg = row_arg;
+        row_best = cur[0]; row_arg = 0;
+        const int16_t *srow = tab[g_class[read[i]]];
+        for (int j = 0; j < F; ++j) {
+            const int32_t up = prev[j + 1] + gf, left = cur[j] + gr, diag = prev[j] + srow[g_class[ref[j]]];
+            int32_t h = up > left ? up : left;
+            if (diag > h) h = diag;
+            cur[j + 1] = h;
+            prow[j + 1] = h == diag ? PTR_DIAG : (h == up ? PTR_UP : PTR_LEFT);
+            if (last_ref == F - 1 && g_class[ref[j]] == 0) last_ref = j - 1;
+            if (h > row_best) { row_best = h; row_arg = j; }
+        }
+        int32_t *t = prev; prev = cur; cur = t;
+    }
+    if (snap_arg < 0) snap_arg = row_arg;
+    *end_i = last_read;
+    *end_j = last_ref < snap_arg ? last_ref : snap_arg;
+}
+
+static void sw_fill_wide(const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
+                         int gr, int gf, int32_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
+    int32_t *prev = rows, *cur = rows + (F + 1);
+    memset(rows, 0, sizeof(int32_t) * 2 * (size_t)(F + 1));
+    int32_t best = 0; int bi = 0, bj = 0;
+    for (int i = 0; i < R; ++i) {
+        const int16_t *srow = tab[g_class[read[i]]];
+        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
+        for (int j = 0; j < F; ++j) {
+            const int32_t up = prev[j + 1] + gf, left = cur[j] + gr, diag = prev[j] + srow[g_class[ref[j]]];
+            int32_t h = up > left ? up : left;
+            if (diag > h) h = diag;
+            if (h < 0) h = 0;
+            cur[j + 1] = h;
+            prow[j + 1] = h == 0 ? PTR_START : (h == diag ? PTR_DIAG : (h == up ? PTR_UP : PTR_LEFT));
+            if (h > best) { best = h; bi = i; bj = j; }
+        }
+        int32_t *t = prev; prev = cur; cur = t;
+    }
+    *end_i = bi; *end_j = bj;
+}
+
+int vref_align_wide(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
+                    const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
+    class_init();
+    if ((opt & 0xF) > 1) return 0;
+    int16_t tab[6][6];
+    subst_init(sc, tab);
+    const int gr = sc->gap_read, gf = sc->gap_ref;
+    const int alg = opt & 0xF, AL = R + F;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(F + 1));
+        uint8_t *ptr = (uint8_t *)malloc((size_t)(R + 1) * (F + 1));
+#pragma omp for schedule(static)
+        for (int p = 0; p < n; ++p) {
+            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
+            memset(ptr, PTR_START, (size_t)(R + 1) * (F + 1));
+            int ei, ej;
+            if (alg == 0) sw_fill_wide(rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
+            else          nw_fill_wide(rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
+            traceback(rd, rf, R, F, ptr, ei, ej, rows_out + (size_t)p * 2 * AL,
+                      rows_out + (size_t)p * 2 * AL + AL, idx_out + (size_t)p * 4);
+        }
+        free(ptr);
+        free(rows);
+    }
+    return n;
+}
+
 /* ------------------------------------------- affine-gap extension (Gotoh) */
 /* Not in the reference.  open_* = cost of the FIRST gap base, ext_* = cost of each
  * further one, so open == ext == g reproduces the linear model exactly.

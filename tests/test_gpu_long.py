@@ -388,3 +388,41 @@ def test_sse_policy_long_reads_live_against_the_sse_kernel():
             got = hip.compute_alignments(opt, reads, refs)
             _same_alignments(got, s.compute_alignments(opt, reads, refs), ("sse live", opt))
             _same_alignments(got, a.compute_alignments(opt, reads, refs), ("avx live", opt))
+
+
+def test_nw_alignments_on_int32_cells_where_int16_would_wrap():
+    """NW-variant alignments whose column-0 border (read_length * gap_ref) leaves int16: the reference's shorts wrap
+    there (DefaultKernel.cpp:282-389); rounds 1-2 refused the call, round 3 computes it on int32 cells (row strips, one
+    pair per register).  Against the oracle's int32 restatement; the Smith-Waterman call of the same object is untouched."""
+    R, F, n = 11000, 10500, 3                       # 11001 * -3 = -33003
+    reads, refs = synth.make_pairs(n, R, F, seed=61, sub_rate=0.1, indel_rate=0.002, n_run_frac=0.4, short_frac=0.4)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4) as hip:
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
+        _same_alignments(got, cpu_ref.align(host.NW, reads, refs, threads=4, wide=True), ("int32 NW", R, F))
+        got = hip.compute_alignments(host.SW, reads, refs, normalise=False)
+        _same_alignments(got, cpu_ref.align(host.SW, reads, refs, threads=4), ("SW beside it", R, F))
+    R, F, n = 9000, 400, 5                          # gap -4: 9001 * -4 = -36004, a short reference
+    reads, refs = synth.make_pairs(n, R, F, seed=62, sub_rate=0.1, n_run_frac=0.2, short_frac=0.2)
+    sc = cpu_ref.Scoring.make(2, -1, -2, -4)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=-2, score_gap_ref=-4, num_threads=4) as hip:
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
+        _same_alignments(got, cpu_ref.align(host.NW, reads, refs, sc, threads=4, wide=True), ("int32 NW", R, F))
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=-2, score_gap_ref=-4, traceback_policy=1) as hip:
+        with pytest.raises(host.PluginError, match="int16"):          # the SSE rules exist on int16 cells only: still refused
+            hip.compute_alignments(host.NW, reads, refs)
+
+
+@pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 71), (64, 128, 300, 72), (33, 70, 101, 73), (1, 1, 5, 74), (700, 90, 40, 75),
+                                         (2049, 300, 7, 76), (3000, 3500, 6, 77)])
+@pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
+def test_int32_alignment_cells_forced(monkeypatch, R, F, n, seed, gaps):
+    """The int32 strip kernel on shapes where int16 suffices (VALIGN_HIP_WIDE_ALIGN): identical to the int16 kernels'
+    alignments and to the oracle -- one strip and many, odd pair counts, padding, invalid bases moving the end cell."""
+    monkeypatch.setenv("VALIGN_HIP_WIDE_ALIGN", "1")
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.1, short_frac=0.15, lowercase_frac=0.05, junk_frac=0.05)
+    sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1], num_threads=3) as hip:
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
+    exp = cpu_ref.align(host.NW, reads, refs, sc, threads=8)
+    _same_alignments(got, exp, ("forced int32", R, F, gaps))
+    _same_alignments(exp, cpu_ref.align(host.NW, reads, refs, sc, threads=8, wide=True), "oracle int16 == int32")

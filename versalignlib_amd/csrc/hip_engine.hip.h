@@ -137,17 +137,21 @@ struct StripGeometry {
     const void *kernel[2];
     const void *affine_kernel[2];      // nullptr: too many rows per lane for the affine kernel's registers
     const void *sse_kernel[2];         // traceback_policy = 1 (linear gaps)
+    const void *wide_kernel;           // NW variant on int32 cells (linear gaps, default tie-breaks); nullptr: too many registers
 };
 #define VALIGN_STRIP_SSE(K) {(const void *)&align_strip_kernel<K, kAlgSW, false, true>, (const void *)&align_strip_kernel<K, kAlgNW, false, true>}
 static const StripGeometry kStripGeometries[] = {
-    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}},
-    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24)},
+    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr},
+    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24), nullptr},
     {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
-     {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}, VALIGN_STRIP_SSE(16)},
+     {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}, VALIGN_STRIP_SSE(16),
+     (const void *)&align_strip_wide_kernel<16>},
     {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
-     {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}, VALIGN_STRIP_SSE(12)},
+     {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}, VALIGN_STRIP_SSE(12),
+     (const void *)&align_strip_wide_kernel<12>},
     {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
-     {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}, VALIGN_STRIP_SSE(8)},
+     {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}, VALIGN_STRIP_SSE(8),
+     (const void *)&align_strip_wide_kernel<8>},
 };
 #undef VALIGN_STRIP_SSE
 
@@ -1016,9 +1020,17 @@ public:
                       short *d_idx, hipStream_t stream, const WalkChain *chain = nullptr) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return false;
+        // NW-variant alignments whose cells leave int16 (the reference's shorts would wrap): int32 cells on the row-strip path,
+        // one pair per register -- linear gaps, default tie-breaks; anything else that leaves the range is refused
+        const bool border_bad = alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000);
+        const bool wide_ok = alg == kAlgNW && !sc_.affine && !sse_policy_;
+        if (wide_ok && (border_bad || !int16_range_ok(alg) || wide_align_)) {
+            hip_check(hipSetDevice(device_), "hipSetDevice");
+            align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream, true);
+            return false;
+        }
         check_int16_range(alg);
-        if (alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000))
-            throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
+        if (border_bad) throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         if (plan_.long_mode) {
             align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
@@ -1212,6 +1224,7 @@ public:
     bool align_fused(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows, short *d_idx,
                      hipStream_t stream) {
         if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg, 256)) return false;     // (256: the tallest fused geometry)
+        if (wide_align_ && alg == kAlgNW) return false;
         try {
             check_int16_range(alg);
         } catch (const std::runtime_error &) {
@@ -1270,7 +1283,7 @@ public:
     // Linear or affine gaps, Default tie-breaks, int16 cells (the reference's; where they would wrap the call is refused
     // by check_int16_range above instead of wrapping silently).
     void align_strips_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
-                             short *d_idx, hipStream_t stream) {
+                             short *d_idx, hipStream_t stream, bool wide = false) {
         const bool affine = sc_.affine;
         if (sse_policy_ && affine)
             throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
@@ -1280,6 +1293,7 @@ public:
             for (const StripGeometry &g : kStripGeometries) {
                 if (affine && !g.affine_kernel[alg]) continue;
                 if (sse_policy_ && !g.sse_kernel[alg]) continue;
+                if (wide && !g.wide_kernel) continue;
                 const WaveLds w = g.lds(64 * g.K, F_);
                 if (w.total <= budget && !geo) {
                     geo = &g;
@@ -1294,7 +1308,7 @@ public:
         const int blocks8 = (F_ + 63 + 7) / 8;
         const int row_dwords = ((F_ + 71) / 64 + 2) * 64;
         const size_t strip_words = (size_t)blocks8 * 64 * K * (affine ? 2 : 1);    // per wave (= pair-of-pairs) and strip
-        const int row_sets = affine ? 2 : 1;                                       // boundary rows: H, and F beside it (affine)
+        const int row_sets = (affine || wide) ? 2 : 1;                             // boundary rows: H, and F beside it (affine); one per pair (int32 cells)
         const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_sets * row_dwords * 4;
         size_t free_b = 0, total_b = 0;
         hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
@@ -1333,7 +1347,7 @@ public:
         hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_,
                            sse_policy_ ? 1 : 0);
         hip_check(hipGetLastError(), "hipLaunchKernel(first_invalid_kernel)");
-        const void *fn = affine ? geo->affine_kernel[alg] : (sse_policy_ ? geo->sse_kernel[alg] : geo->kernel[alg]);
+        const void *fn = wide ? geo->wide_kernel : (affine ? geo->affine_kernel[alg] : (sse_policy_ ? geo->sse_kernel[alg] : geo->kernel[alg]));
         if (lds.total > kDefaultBlockLds)
             hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds.total),
                       "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -2086,6 +2100,7 @@ private:
     std::unique_ptr<CopyIssuer> copy_issuer_;
     bool ramp_ = getenv("VALIGN_HIP_NO_RAMP") == nullptr;                 // tuning switch: every chunk of a host-pointer call full-sized
     int split_parts_ = getenv("VALIGN_HIP_SPLIT_PARTS") ? atoi(getenv("VALIGN_HIP_SPLIT_PARTS")) : 2;   // tuning switch: > 2: geometric parts of align_device
+    bool wide_align_ = getenv("VALIGN_HIP_WIDE_ALIGN") != nullptr;         // test switch: NW alignments (linear gaps, default tie-breaks) on int32 cells always
     bool no_direct_out_ = getenv("VALIGN_HIP_NO_DIRECT_OUT") != nullptr;   // tuning switch: stage + scatter even into registered result buffers
     bool no_overlap_ = getenv("VALIGN_HIP_NO_OVERLAP") != nullptr;   // tuning switch: tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = getenv("VALIGN_HIP_SCRATCH_CAP_MB") ? atoll(getenv("VALIGN_HIP_SCRATCH_CAP_MB")) : 0;   // test switch: small pointer scratch

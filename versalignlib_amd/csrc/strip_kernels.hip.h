@@ -425,4 +425,131 @@ align_strip_kernel(const StripArgs args) {
     }
 }
 
+// ---- int32 cells (round 3): NW-variant alignments whose cells leave int16 ----
+// The reference's shorts wrap where read_length * gap_ref (the NW variant's column-0 border) or a long mismatching stretch
+// goes below -32768 (DefaultKernel.cpp:282-389 computes in short); rounds 1-2 refused such calls.  Same strips, same
+// pointer stream, same traceback -- with ONE pair per register: the wave sweeps the strip twice, pair A then pair B.
+// Pass A stores its 2-bit codes in the low halves of the stream's words, pass B reads them back and adds its high halves
+// (the same lane wrote them: no ordering question).  Boundary rows: one int32 row per pair (StripArgs top / bottom for pair
+// A, top_f / bottom_f for pair B -- the slots the affine kernel uses for F).  Linear gaps, default tie-breaks.
+template <int K>
+__global__ void __launch_bounds__(64)
+align_strip_wide_kernel(const StripArgs args) {
+    constexpr int G = 64;
+    using geo = Geo<G, K>;
+    const int lane = threadIdx.x;
+    const int l = lane;
+    const int R = args.R, F = args.F;
+    const int pad_total = args.strips * geo::kRows - R;
+    const int row0 = args.strip * geo::kRows - pad_total;
+    const int strip_pad = args.strip * geo::kRows;
+
+    WaveTables w;
+    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+                                 args.wave_lds, args.match, args.mismatch, w, false, blockIdx.x, 0, row0))
+        return;
+    const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    const int g_read = args.gap_read, g_ref = args.gap_ref;
+    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
+    const long long pp = w.pair0 / 2;
+    const bool has_top = args.strip > 0, has_bottom = args.strip + 1 < args.strips;
+    const int steps = args.blocks8 * 8;
+
+    for (int half = 0; half < 2; ++half) {
+        const long long pair = w.pair0 + half;
+        const long long p_src = w.pair0 + (half > w.last ? w.last : half);
+        const int ir = args.first_bad[2 * p_src], jr = args.first_bad[2 * p_src + 1];
+        const unsigned *top = (half ? args.top_f : args.top) + pp * args.row_dwords;
+        unsigned *bottom = (half ? args.bottom_f : args.bottom) + pp * args.row_dwords;
+        // the one row whose arg-max the end-cell rule needs: the last valid read row (DefaultKernel.cpp:307-315, 381-387)
+        const int tracked = ir >= 1 ? ir - 1 + pad_total - strip_pad : -1;          // row of this strip, or outside [0, 64 K)
+        const int tr_lane = tracked >= 0 ? tracked / K : -1, tr_q = tracked >= 0 ? tracked % K : -1;
+
+        int Hl[K];
+        unsigned code[K], acc[K];
+        int row_best = 0, row_col = l;                      // fc semantics of align_strip_kernel: step index of the arg-max
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int pos = row0 + l * K + q;
+            Hl[q] = pos < 0 ? 0 : (pos + 1) * g_ref;      // column 0: a gap of pos + 1 read bases
+            code[q] = acc[q] = 0u;
+            if (l == tr_lane && q == tr_q) row_best = Hl[q];
+        }
+        int h_last = Hl[K - 1];
+        int up0 = (l == 0 && row0 - 1 >= 0) ? row0 * g_ref : 0;      // row above the strip at column -1
+        int j = -l;
+        unsigned code_addr = lds_offset(w.refc) - 2 * l;
+        unsigned top_cur = 0u, top_next = has_top ? top[lane] : 0u;
+        unsigned bot_acc = 0u;
+
+        for (int t = 0; t < steps; ++t) {
+            if ((t & 63) == 0) {
+                top_cur = top_next;
+                top_next = (has_top && t + 64 + lane < args.row_dwords) ? top[t + 64 + lane] : 0u;
+            }
+            const int diag0 = up0;
+            const int above = __builtin_amdgcn_readlane((int)top_cur, t & 63);
+            int from_lane = __builtin_amdgcn_update_dpp(0, h_last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            asm volatile("" : "+v"(from_lane));
+            up0 = l == 0 ? above : from_lane;
+            if ((unsigned)j < (unsigned)F) {
+                const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
+                s16x2 S[K];
+                fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
+                int h = up0, d_prev = diag0;
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    const int d = d_prev + (int)(half ? S[q].y : S[q].x);
+                    const int lg = Hl[q] + g_read, ug = h + g_ref;
+                    d_prev = Hl[q];
+                    int m = lg > ug ? lg : ug;
+                    m = d > m ? d : m;
+                    h = m;
+                    Hl[q] = m;
+                    code[q] = m == d ? 0u : (m == ug ? 1u : 2u);          // DIAG > UP > LEFT
+                    if (l == tr_lane && q == tr_q && m > row_best) {      // strictly greater: the first arg-max wins
+                        row_best = m;
+                        row_col = t;
+                    }
+                }
+                h_last = h;
+            }
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = ((acc[q] << 2) | code[q]) & 0xFFFFu;
+            if ((t & 7) == 7) {
+                unsigned *dst = pointer_stream_block<K>(ptr_lane, t >> 3);
+                unsigned w8[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) w8[q] = half ? (dst[q] & 0xFFFFu) | (acc[q] << 16) : acc[q];
+                store_block_words<K>(dst, w8);
+            }
+            if (has_bottom) {
+                const int col = t - (G - 1);
+                if (col >= 0) {
+                    const int v = __builtin_amdgcn_readlane(h_last, G - 1);
+                    bot_acc = lane == (col & 63) ? (unsigned)v : bot_acc;
+                    if ((col & 63) == 63 || t == steps - 1) bottom[(col & ~63) + lane] = bot_acc;
+                }
+            }
+            ++j;
+            code_addr += 2;
+        }
+
+        // ---- end cell: the strip that holds the last valid read row writes it (strip 0 when there is none) ----
+        const int i_end = ir - 1;
+        const int owner = i_end >= 0 ? (i_end + pad_total) / geo::kRows : 0;
+        if (owner == args.strip) {
+            int arg_col = 0;
+            if (i_end >= 0) arg_col = __shfl(row_col - l, tr_lane, kWave);
+            const int last_ref = jr - 1;
+            EndCell out;
+            out.pad = 0;
+            out.score = 0;
+            out.read_pos = (short)i_end;
+            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+            if (l == 0 && pair < args.n) args.ends[pair] = out;
+        }
+    }
+}
+
 }  // namespace valign
