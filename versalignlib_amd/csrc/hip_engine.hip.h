@@ -1508,6 +1508,24 @@ public:
             if (!copy_issuer_) copy_issuer_.reset(new CopyIssuer(device_));
             copy_issuer = copy_issuer_.get();
         }
+        // An error in the middle of the pipeline must not leave copies in flight into the CALLER's buffers (registered
+        // result buffers receive them directly): quiesce the issuer and the streams before the exception leaves.
+        struct Quiesce {
+            Engine *e;
+            bool armed = true;
+            ~Quiesce() {
+                if (!armed) return;
+                if (e->copy_issuer_) {
+                    try {
+                        e->copy_issuer_->wait_idle();
+                    } catch (...) {
+                    }
+                }
+                if (e->trace_stream_) (void)hipStreamSynchronize(e->trace_stream_);
+                for (int s = 0; s < kSlots; ++s) (void)hipStreamSynchronize(e->streams_[s]);
+                for (int s = 0; s < kSlots; ++s) e->slot_pending_[s] = 0;
+            }
+        } quiesce{this};
         for (long long begin = 0; begin < n; begin += chunk, slot = (slot + 1) % kSlots) {
             const long long cnt = std::min<long long>(chunk, n - begin);
             auto t0 = std::chrono::steady_clock::now();
@@ -1550,6 +1568,7 @@ public:
             host_stats_.wait_ms += ms_between(t0, std::chrono::steady_clock::now());
             drain(s);
         }
+        quiesce.armed = false;               // (everything has been waited for)
     }
 
     // host-side phases of the last score_host / align_host call
