@@ -318,8 +318,8 @@ def test_alignments_of_long_reads(R, F, n, seed, gaps):
 
 def test_alignments_config5_shape():
     """10 kbp x 10 kbp alignments of both modes (five strips of 2048 rows): with the default scores the cells stay
-    inside int16 (column 0 of the NW variant reaches -30 003); gap scores of -4 would leave it, which is refused
-    instead of wrapping like the reference's shorts do."""
+    inside int16 (column 0 of the NW variant reaches -30 003); gap scores of -4 leave it -- where the reference's
+    shorts wrap, the NW variant now runs on int32 cells (round 3; rounds 1-2 refused the call)."""
     R = F = 10000
     n = 3
     reads, refs = synth.make_pairs(n, R, F, seed=61, sub_rate=0.1, indel_rate=0.01, n_run_frac=0.3, short_frac=0.34)
@@ -327,9 +327,10 @@ def test_alignments_config5_shape():
         for opt in (host.SW, host.NW):
             got = hip.compute_alignments(opt, reads, refs, normalise=False)
             _same_alignments(got, cpu_ref.align(opt, reads, refs, threads=8), ("10k", opt))
+    sc = cpu_ref.Scoring.make(2, -1, -4, -4)
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, score_gap_read=-4, score_gap_ref=-4) as hip:
-        with pytest.raises(host.PluginError, match="int16 range"):
-            hip.compute_alignments(host.NW, reads, refs)
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
+        _same_alignments(got, cpu_ref.align(host.NW, reads, refs, sc, threads=8, wide=True), "10k, gap -4: int32 cells")
 
 
 @pytest.mark.parametrize("R,F,n,seed", [(3000, 3500, 7, 11), (2500, 700, 9, 12), (2049, 300, 5, 13), (4100, 6000, 3, 14)])
