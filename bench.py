@@ -452,9 +452,10 @@ def abi_leg(reads, refs, threads, devices=1):
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
         k.score_alignments(0, h_reads[:65536], h_refs[:65536], scattered=True)
         k.score_alignments(0, h_reads, h_refs, scattered=True)
-        secs = sorted(k.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(4))
+        secs = sorted(k.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(8))
         phases = [ln for ln in k.drain_log().splitlines() if "score done" in ln]
-        out["score_alignments_sw"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1),
+        out["score_alignments_sw"] = {"ms": round(secs[0] * 1e3, 2), "ms_median_of_8": round(secs[4] * 1e3, 2),
+                                      "gcups": round(n * R * F / secs[0] / 1e9, 1),
                                       "transport": "4-bit base classes (host_packing = 1, default)",
                                       "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
     if devices > 1:
