@@ -237,10 +237,16 @@ public:
         });
     }
 
+    // result rows are copied by one thread below 768 KB (waking the pool costs what copying that much does): 2,048 pairs of
+    // 64 x 128, 590 pairs of 150 x 500 -- a call of 1,000 pairs of 150 x 500 spent 58 us copying 1.3 MB alone
+    static long long serial_below_for_rows(size_t AL) {
+        return std::max<long long>(64, (768ll << 10) / (2 * (long long)std::max<size_t>(AL, 1)));
+    }
+
     // staging -> the caller's contiguous buffers
     void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
         const size_t AL = sink.AL;
-        for_ranges(threads, cnt, 2048, [=](int, long long lo, long long hi) {
+        for_ranges(threads, cnt, serial_below_for_rows(AL), [=](int, long long lo, long long hi) {
             memcpy(sink.rows + (size_t)lo * 2 * AL, rows + (size_t)lo * 2 * AL, (size_t)(hi - lo) * 2 * AL);
             memcpy(sink.idx + 4 * lo, idx + 4 * lo, sizeof(short) * 4 * (size_t)(hi - lo));
         });
@@ -250,7 +256,7 @@ public:
     template <typename AlignmentT>
     void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
         const size_t AL = (size_t)R_ + F_;
-        for_ranges(threads, cnt, 2048, [=](int, long long lo, long long hi) {
+        for_ranges(threads, cnt, serial_below_for_rows(AL), [=](int, long long lo, long long hi) {
             for (long long i = lo; i < hi; ++i) {
                 AlignmentT &a = alignments[i];
                 a.read = new char[AL ? AL : 1];

@@ -589,10 +589,26 @@ __host__ __device__ inline FusedLds<G, K> fused_lds(int wave_lds, int R, int F, 
     auto up16 = [](int v) { return (v + 15) / 16 * 16; };
     FusedLds<G, K> f;
     f.ptr = up16(wave_lds);
-    f.reads = f.ptr + up16(blocks8 * kWave * K * 4);
-    f.refs = f.reads + up16(geo::kPairs * ((R + 3) & ~3));        // each sequence starts at a dword: the walk loads bases four at a time
-    f.rows = f.refs + up16(geo::kPairs * ((F + 3) & ~3));
-    f.ends = f.rows + up16(geo::kPairs * 2 * (R + F) + 4);
+    const int ptr_end = f.ptr + up16(blocks8 * kWave * K * 4);
+    const int reads_bytes = up16(geo::kPairs * ((R + 3) & ~3));    // each sequence starts at a dword: the walk loads bases four at a time
+    const int refs_bytes = up16(geo::kPairs * ((F + 3) & ~3));
+    const int rows_bytes = up16(geo::kPairs * 2 * (R + F) + 4);
+    // What the walk needs beside the pointer stream -- the sequences and the result rows of the wave's pairs -- is staged once
+    // the fill is over and the end cells are written: the query profile and the reference codes (the wave's tables, the
+    // first `wave_lds` bytes) are dead by then, so the walk's buffers lie over them where they fit.  At 150 x 500 on 64 x 4
+    // that takes the block from 82.6 KB to 78.7 KB: two blocks per CU instead of one, and a call of 1,000 pairs (500 blocks
+    // on 256 CUs) is one round instead of two.
+    if (reads_bytes + refs_bytes + rows_bytes <= f.ptr) {
+        f.reads = 0;
+        f.refs = reads_bytes;
+        f.rows = reads_bytes + refs_bytes;
+        f.ends = ptr_end;
+    } else {
+        f.reads = ptr_end;
+        f.refs = f.reads + reads_bytes;
+        f.rows = f.refs + refs_bytes;
+        f.ends = f.rows + rows_bytes;
+    }
     f.total = f.ends + up16(geo::kPairs * (int)sizeof(EndCell));
     return f;
 }
