@@ -134,14 +134,17 @@ int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb);
  * Scores beyond the ABI's short saturate at 32767.                                               */
 int valign_hip_set_score_width(valign_hip_engine *e, int bits);
 
-/* Length-sorted batching of valign_hip_score_host / score_alignments (Smith-Waterman and the NW variant): the
- * reference host pads every sequence to the longest (src/util/versalignUtil.cpp:17-33) and every
- * backend sweeps the padding; here pairs are binned by their length without trailing non-ACGT
- * bytes and each bin is swept at its own shape.  Scores are identical: trailing padding scores 0, so it
- * cannot raise a Smith-Waterman maximum, and every value of the real matrix's last row / column runs
+/* Length-sorted batching of score calls (Smith-Waterman and the NW variant; valign_hip_score_host / score_alignments
+ * and valign_hip_score_device): the reference host pads every sequence to the longest
+ * (src/util/versalignUtil.cpp:17-33) and every backend sweeps the padding; here pairs are binned by their length
+ * without trailing non-ACGT bytes and each bin is swept at its own shape.  Scores are identical: trailing padding
+ * scores 0, so it cannot raise a Smith-Waterman maximum, and every value of the real matrix's last row / column runs
  * down its diagonal unchanged to the padded matrix's, which is where the NW variant reads its result.
- * Sorting costs the host one more pass over the sequence tails: 0 = never (default), 1 = when a sample of
- * the call says a third of the cells would be skipped, 2 = always.                                     */
+ * Classification, packing by length class and the scores' way back run on the device.  0 = never (default), 1 = when the
+ * call is ragged enough to skip a third of the cells (host pointers: judged from a sample of the call's tails;
+ * valign_hip_score_device: from the device's histogram), 2 = always.  With mode 1 or 2 valign_hip_score_device WAITS
+ * for the classification of the batch before it launches the sweeps (the rest is asynchronous on `stream` as ever)
+ * and uses scratch of the engine: such calls on one engine go on one stream at a time.                        */
 int valign_hip_set_ragged_batching(valign_hip_engine *e, int mode);
 
 /* Score n pairs that are already in device memory: d_reads = n*read_length bytes and

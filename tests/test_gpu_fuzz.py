@@ -91,6 +91,21 @@ def test_random_configuration(case, monkeypatch):
         hrows, hidx = eng.align_host(opt, reads, refs, threads=2)
         assert np.array_equal(hidx, eidx) and np.array_equal(hrows, erows), (c, "align_host", opt, eng.describe(opt, n)["direct_call"])
     eng.close()
+    if case % 4 == 1:
+        # length-sorted batching on the device (ragged_kernels.hip.h): mixed-length pairs, every configuration's scoring,
+        # device-resident and through the host pipeline -- identical to the padded sweep
+        monkeypatch.setenv("VALIGN_HIP_RAGGED_MIN", "8")
+        rr, rf = synth.make_ragged_pairs(n, R, F, seed=c["seed"] + 7, n_run_frac=0.05, short_frac=0.05, junk_frac=0.03)
+        eng = hipkernel.Engine(R, F, hsc)
+        eng.set_ragged_batching(2)
+        dr, df = torch.from_numpy(rr).cuda(), torch.from_numpy(rf).cuda()
+        for opt in (host.SW, host.NW):
+            exp = cpu_ref.score(opt, rr, rf, osc, threads=8, affine=affine)
+            got = eng.score_device(opt, dr, df).cpu().numpy()
+            assert np.array_equal(got, exp), (c, "ragged score_device", opt, np.nonzero(got != exp)[0][:6], eng.describe(opt, n)["ragged_launches"])
+            got = eng.score_host(opt, rr, rf, threads=3)
+            assert np.array_equal(got, exp), (c, "ragged score_host", opt, np.nonzero(got != exp)[0][:6])
+        eng.close()
     if not affine and case % 2 == 0:
         # banded Smith-Waterman scores on the cyclic block chain (band_kernels.hip.h) -- or on the strips where the plan
         # says the chain does not fit: the library reports which block shape it computes

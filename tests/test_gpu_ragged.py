@@ -1,7 +1,8 @@
-"""Length-sorted batching: Smith-Waterman score calls that arrive with ragged,
-NUL-padded sequences are binned by trimmed length and swept at the bin's shape.  The scores must be
-exactly those of the padded sweep -- checked against the oracle and against the same library with the
-feature switched off -- and the engine must report that it swept fewer cells."""
+"""Length-sorted batching: score calls that arrive with ragged, NUL-padded sequences are binned by
+trimmed length ON THE DEVICE (ragged_kernels.hip.h: classification, packing by length class, one sweep per read class,
+scores back in the caller's order) and swept at the bin's shape -- host-pointer calls chunk by chunk inside the pipeline,
+device-resident batches in place.  The scores must be exactly those of the padded sweep -- checked against the oracle and
+against the same library with the feature switched off -- and the engine must report that it swept fewer cells."""
 import os
 
 import numpy as np
@@ -128,4 +129,54 @@ def test_all_empty_sequences():
     refs = np.zeros((n, F), dtype=np.uint8)
     eng = hipkernel.Engine(R, F)
     assert not eng.score_host(host.SW, reads, refs).any()
+    eng.close()
+
+
+@pytest.mark.parametrize("alg", [host.SW, host.NW])
+@pytest.mark.parametrize("R,F,n", [(150, 500, 30011), (64, 128, 9000), (37, 301, 4500)])
+def test_ragged_device_resident_batch(small_bins, alg, R, F, n):
+    """valign_hip_score_device on a batch that is already in HBM: classified, packed and swept by length class there."""
+    import torch
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=51 + R, n_run_frac=0.03, short_frac=0.02, junk_frac=0.02)
+    reads[7] = 0                                   # a pair of nothing but padding
+    refs[7] = 0
+    refs[11] = ord("N")                            # ... and a reference of nothing but N
+    exp = cpu_ref.score(alg, reads, refs, threads=8)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    eng = hipkernel.Engine(R, F)
+    plain = eng.score_device(alg, d_reads, d_refs).cpu().numpy()
+    assert np.array_equal(plain, exp)
+    for mode in (2, 1):
+        eng.set_ragged_batching(mode)
+        got = eng.score_device(alg, d_reads, d_refs).cpu().numpy()
+        info = eng.describe(alg, n)
+        assert np.array_equal(got, exp), (mode, np.nonzero(got != exp)[0][:8])
+        assert info["ragged_launches"] > 1 and info["ragged_cell_fraction"] < (0.75 if R >= 64 else 1.0), info
+    # a batch of full-length pairs: mode 1 looks at the device's histogram and sweeps the batch as it stands
+    reads, refs = synth.make_pairs(n, R, F, seed=52, n_run_frac=0.0, short_frac=0.0)
+    d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
+    got = eng.score_device(alg, d_reads, d_refs).cpu().numpy()
+    assert eng.describe(alg, n)["ragged_launches"] == 0
+    assert np.array_equal(got, cpu_ref.score(alg, reads, refs, threads=8))
+    eng.close()
+
+
+@pytest.mark.parametrize("packing", [1, 0])
+def test_ragged_chunks_of_the_pipeline(small_bins, monkeypatch, packing):
+    """Several chunks in flight: every chunk is classified while the host gathers the next one and swept one iteration
+    later; affine scoring, both modes, 4-bit classes and ASCII across PCIe."""
+    monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(1 << 20))          # ~1,600 pairs of 150 x 500 per chunk
+    R, F, n = 150, 500, 23017
+    reads, refs = synth.make_ragged_pairs(n, R, F, seed=53, n_run_frac=0.03, short_frac=0.02, junk_frac=0.02)
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)
+    eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1))
+    eng.set_host_packing(packing)
+    eng.set_ragged_batching(2)
+    for alg in (host.SW, host.NW):
+        exp = cpu_ref.score(alg, reads, refs, sc, threads=8, affine=True)
+        for threads in (1, 5):
+            got = eng.score_host(alg, reads, refs, threads=threads)
+            assert np.array_equal(got, exp), (alg, threads, np.nonzero(got != exp)[0][:8])
+        info = eng.describe(alg, n)
+        assert info["ragged_launches"] > 10 and info["ragged_cell_fraction"] < 0.75 and info["packed_classes"] == packing, info
     eng.close()

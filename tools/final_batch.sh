@@ -31,7 +31,9 @@ bash tools/pmc_align.sh > $OUT/pmc_align.log 2>&1
 python tools/pmc_summary.py $R/gpurun_out/pmc_align > $OUT/pmc_align.json || exit 1
 echo "align pmc done"
 { echo "# tools/latency_phases.py (flat entry points, engine-reported phases)"; python tools/latency_phases.py;
-  echo "# tools/latency_bench.py (plugin ABI)"; python tools/latency_bench.py; } 2>&1 | grep -v amdgpu.ids > $OUT/latency.txt || exit 1
+  echo "# tools/latency_bench.py 1 (plugin ABI, num_threads = 1)"; python tools/latency_bench.py 1;
+  echo "# tools/latency_bench.py 16 (plugin ABI, num_threads = 16: result rows of calls above 768 KB are copied by the pool)"; python tools/latency_bench.py 16;
+  echo "# tools/first_call.py: cold process -> first results, and a second spawn in the warm process"; python tools/first_call.py; } 2>&1 | grep -v amdgpu.ids > $OUT/latency.txt || exit 1
 { echo "# long reads: 2.5k x 5k (65536 pairs), 10k x 10k (32768 pairs = one GPU's share of BASELINE config 5), banded (512), affine";
   python tools/geom_sweep.py --R 2500 --F 5000 --n 65536 --iters 2 --geoms 0x0;
   python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0;

@@ -30,7 +30,7 @@ HIP_SOURCES = ["hip_plugin.hip"]
 HIP_KERNEL_PART = "kernel_part.hip"          # compiled once per part (kernel_instances.hip.h), in parallel
 HIP_KERNEL_PARTS = 7
 HIP_DEPS = ["hip_plugin.hip", "kernel_part.hip", "kernel_instances.hip.h", "dp_kernels.hip.h", "trace_kernels.hip.h",
-            "long_kernels.hip.h", "strip_kernels.hip.h", "hip_engine.hip.h", "host_pipeline.h", "band_kernels.hip.h", "pack_kernels.hip.h"]
+            "long_kernels.hip.h", "strip_kernels.hip.h", "hip_engine.hip.h", "host_pipeline.h", "band_kernels.hip.h", "pack_kernels.hip.h", "ragged_kernels.hip.h"]
 OBJ = os.path.join(PKG, "build")             # intermediate objects (git-ignored)
 HOST_SOURCES = ["valign_host.cpp"]
 

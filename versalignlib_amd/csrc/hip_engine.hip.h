@@ -29,6 +29,7 @@
 #include "band_kernels.hip.h"
 #include "long_kernels.hip.h"
 #include "pack_kernels.hip.h"
+#include "ragged_kernels.hip.h"
 #include "strip_kernels.hip.h"
 
 namespace valign {
@@ -339,7 +340,7 @@ public:
         int launches = 0;
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
-        double classify_ms = 0;                              // part of gather_ms: trimmed lengths + binning
+        double classify_ms = 0;                              // length-sorted batching: host time spent waiting for the device's histograms
         int packed = 0;                                      // 1: the sequences crossed PCIe as 4-bit classes
         int direct_out = 0;                                  // 1: results were copied straight into the caller's (registered) buffers
         int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly; 2: ... in one fused launch
@@ -385,6 +386,7 @@ public:
         if (d_brow_) (void)hipFree(d_brow_);
         if (d_band_blocks_) (void)hipFree(d_band_blocks_);
         if (d_band_fill_) (void)hipFree(d_band_fill_);
+        release_ragged();
         for (int s = 0; s < kSlots; ++s) {
             if (slot_done_[s]) (void)hipEventDestroy(slot_done_[s]);
             if (in_done_[s]) (void)hipEventDestroy(in_done_[s]);
@@ -420,11 +422,10 @@ public:
         if (policy != 0 && policy != 1) throw std::runtime_error("traceback_policy must be 0 (default) or 1 (sse)");
         sse_policy_ = policy == 1;
     }
-    // Length-sorted batching of Smith-Waterman score calls that arrive as host pointers:
-    // 0 = never (every pair is swept at read_length x ref_length; default -- the host's pass over every
-    // sequence tail costs more wall time than the skipped cells save while the host gather is the limit,
-    // profiles/r01_host_path.txt), 1 = when a sample of the call's pairs says it would skip a third of
-    // the cells, 2 = always
+    // Length-sorted batching of score calls (both modes), done on the device -- classification, packing by length class,
+    // one sweep per read class (ragged_kernels.hip.h): 0 = never (every pair is swept at read_length x ref_length; default),
+    // 1 = when the call is ragged enough to skip a third of the cells (host pointers: judged from a sample of the call's
+    // tails; device-resident batches: from the device's own histogram, which the call then waits for), 2 = always
     void set_ragged_batching(int mode) {
         if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
         ragged_ = mode;
@@ -448,16 +449,25 @@ public:
     hipStream_t own_stream() const { return streams_[0]; }
 
     // Device-resident batch, asynchronous on `stream`.
+    // `length_sorted` false: the caller has decided about length-sorted batching itself (the chunk pipeline of score_host)
     void score_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs,
-                      int16_t *d_scores, hipStream_t stream) {
+                      int16_t *d_scores, hipStream_t stream, bool length_sorted = true) {
         const int alg = opt & 0xF;
         if (alg > 1 || n <= 0) return;          // reference: unsupported mode is a silent no-op
         hip_check(hipSetDevice(device_), "hipSetDevice");
+        if (length_sorted) host_stats_ = HostStats{};
         if (score_width_ == 16) check_int16_range(alg, true);
         const bool wide = score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg));
         if (plan_.long_mode || wide) {      // int32 cells exist on the strip path only
             score_long_device(alg, n, d_reads, d_refs, d_scores, stream, wide);
             return;
+        }
+        // ragged_batching on a device-resident batch: classify, pack and sweep by length class (ragged_kernels.hip.h).  The
+        // call then WAITS for the classification (the host lays the groups out); mode 1 sweeps the batch as it stands when
+        // the length classes would not skip a third of the cells.
+        if (length_sorted && ragged_applies(alg) && ragged_fits(n) && n >= 2 * ragged_min_) {
+            ragged_begin(0, n, d_reads, d_refs, stream);
+            if (ragged_finish(0, alg, n, d_scores, stream, ragged_ == 2)) return;
         }
         // a batch that leaves most SIMDs with at most one wave is over when its slowest wave is: shortest sweep
         const bool few = n <= (long long)latency_plan_.pairs_per_wave * 1024 && band_width_ == 0;
@@ -907,7 +917,10 @@ public:
             host_stats_.direct = 1;
             return;
         }
-        const bool ragged = !d_dest && ragged_applies(alg) && (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
+        // length-sorted batching: the decision is the host's (a sample of the call's tails), the work the device's -- every chunk
+        // is classified, packed by length class and swept class by class in HBM (ragged_kernels.hip.h)
+        const bool ragged = !d_dest && ragged_applies(alg) && ragged_fits(chunk) &&
+                            (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
         const bool shared_scratch = plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg);
         host_stats_ = HostStats{};
         auto drain = [&](int s) {
@@ -916,15 +929,21 @@ public:
                 slot_pending_[s] = 0;
                 return;
             }
-            short *dst = scores + slot_begin_[s];
-            if (slot_ragged_[s]) {
-                const int *pos = pos_[s].data();
-                for (long long i = 0; i < slot_pending_[s]; ++i) dst[i] = h_scores_[s][pos[i]];
-            } else {
-                memcpy(dst, h_scores_[s], sizeof(short) * (size_t)slot_pending_[s]);
-            }
+            memcpy(scores + slot_begin_[s], h_scores_[s], sizeof(short) * (size_t)slot_pending_[s]);
             slot_pending_[s] = 0;
         };
+        // what follows a chunk's kernels: the scores' way home and the slot's event.  A length-sorted chunk gets there one
+        // iteration late: its classification runs on the device while the host gathers the next chunk, and only then does
+        // the host read the histogram, lay the groups out and launch the sweeps (ragged_finish) -- no wait in between.
+        auto finish_chunk = [&](int s, long long pairs) {
+            hipStream_t cs = streams_[shared_scratch ? 0 : s];
+            if (ragged) (void)ragged_finish(s, alg, pairs, d_scores_[s], cs, true);
+            if (!d_dest)
+                hip_check(hipMemcpyAsync(h_scores_[s], d_scores_[s], sizeof(short) * (size_t)pairs, hipMemcpyDeviceToHost, cs), "D2H scores");
+            hip_check(hipEventRecord(slot_done_[s], cs), "hipEventRecord");
+        };
+        int open_slot = -1;                        // the length-sorted chunk whose sweeps are not launched yet
+        long long open_pairs = 0;
         int slot = 0;
         // Ramp: the device idles until the first chunk is gathered and copied, so the first chunks are short (a quarter,
         // then half a chunk); chunks of many calls deep in the pipeline stay large (fewer launches, full waves).
@@ -941,29 +960,8 @@ public:
             host_stats_.drain_ms += ms_between(t1, t2);
             // kernels that share a scratch (strip boundary rows) stay on one stream
             hipStream_t st = streams_[shared_scratch ? 0 : slot];
-            if (ragged) {
-                const std::vector<LengthGroup> groups = gather_ragged(reads + begin, refs + begin, cnt, slot, threads);
-                host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
-                size_t read_bytes = 0, ref_bytes = 0;
-                for (const LengthGroup &g : groups) {
-                    read_bytes = std::max(read_bytes, g.read_ofs + (size_t)g.pairs * g.R);
-                    ref_bytes = std::max(ref_bytes, g.ref_ofs + (size_t)g.pairs * g.F);
-                }
-                hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], read_bytes, hipMemcpyHostToDevice, st), "H2D reads");
-                hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], ref_bytes, hipMemcpyHostToDevice, st), "H2D refs");
-                // one launch per read class: its reference-length groups ride in the kernel's group table
-                for (size_t first = 0; first < groups.size();) {
-                    size_t end = first;
-                    int widest = 0;
-                    while (end < groups.size() && groups[end].R == groups[first].R) widest = std::max(widest, groups[end++].F);
-                    launch_score(class_plan(groups[first].R, widest), alg, groups[first].R, widest, 0, d_reads_[slot],
-                                 d_refs_[slot], d_scores_[slot], st, groups.data() + first, (int)(end - first));
-                    host_stats_.launches += 1;
-                    first = end;
-                }
-                for (const LengthGroup &g : groups) host_stats_.cells_swept += (double)g.pairs * g.R * g.F;
-                host_stats_.cells_padded += (double)cnt * R_ * F_;
-            } else if (pack_) {
+            const bool sweep_now = !ragged;
+            if (pack_) {
                 // two base classes per byte across PCIe, expanded in HBM to the canonical byte of each class
                 const size_t PR = packed_length(R_), PF = packed_length(F_);
                 packer_.gather_packed(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
@@ -972,22 +970,26 @@ public:
                 hip_check(hipMemcpyAsync(d_pack_refs_[slot], h_refs_[slot], (size_t)cnt * PF, hipMemcpyHostToDevice, st), "H2D refs (classes)");
                 launch_unpack(d_pack_reads_[slot], d_reads_[slot], cnt, R_, st);
                 launch_unpack(d_pack_refs_[slot], d_refs_[slot], cnt, F_, st);
-                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_dest ? d_dest + begin : d_scores_[slot], st);
                 host_stats_.packed = 1;
             } else {
                 gather(reads + begin, refs + begin, cnt, h_reads_[slot], h_refs_[slot], threads);
                 host_stats_.gather_ms += ms_between(t2, std::chrono::steady_clock::now());
                 hip_check(hipMemcpyAsync(d_reads_[slot], h_reads_[slot], (size_t)cnt * R_, hipMemcpyHostToDevice, st), "H2D reads");
                 hip_check(hipMemcpyAsync(d_refs_[slot], h_refs_[slot], (size_t)cnt * F_, hipMemcpyHostToDevice, st), "H2D refs");
-                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_dest ? d_dest + begin : d_scores_[slot], st);
             }
-            if (!d_dest)
-                hip_check(hipMemcpyAsync(h_scores_[slot], d_scores_[slot], sizeof(short) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H scores");
-            hip_check(hipEventRecord(slot_done_[slot], st), "hipEventRecord");
+            if (sweep_now) {
+                score_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_dest ? d_dest + begin : d_scores_[slot], st, false);
+                finish_chunk(slot, cnt);
+            } else {
+                ragged_begin(slot, cnt, d_reads_[slot], d_refs_[slot], st);
+                if (open_slot >= 0) finish_chunk(open_slot, open_pairs);
+                open_slot = slot;
+                open_pairs = cnt;
+            }
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;
-            slot_ragged_[slot] = ragged;
         }
+        if (open_slot >= 0) finish_chunk(open_slot, open_pairs);
         for (int k = 0; k < kSlots; ++k) {          // oldest chunk first
             const int s = (slot + k) % kSlots;
             auto t0 = std::chrono::steady_clock::now();
@@ -1768,7 +1770,6 @@ private:
             (void)hipStreamSynchronize(streams_[s]);
             slot_pending_[s] = 0;
             slot_begin_[s] = 0;
-            slot_ragged_[s] = false;
         }
     }
 
@@ -1972,42 +1973,97 @@ private:
         packer_.for_ranges(threads, cnt, serial_below, fn);
     }
 
-    // Bin the chunk's pairs by trimmed length class, fold bins too small to be worth it into
-    // the next larger one, and copy every pair to its place in the pinned slot.  pos_[slot][i] is
-    // the position of pair i in the packed order.
-    std::vector<LengthGroup> gather_ragged(const char *const *reads, const char *const *refs, long long cnt, int slot,
-                                           int threads) {
+    // ---- length-sorted batching on the device (ragged_kernels.hip.h) ----
+    // One context per pipeline slot (chunks of different slots are in flight side by side); context 0 also serves
+    // device-resident batches (score_device).
+    struct RaggedCtx {
+        long long cap = 0;                     // pairs the buffers hold
+        uint8_t *reads = nullptr, *refs = nullptr;     // the packed groups
+        int16_t *scores = nullptr;             // ... and their scores, packed order
+        uint16_t *bin = nullptr;               // length bin of every pair
+        int *pos = nullptr;                    // packed place of every pair
+        unsigned *counters = nullptr;          // bins' pair counts, then the groups' fill cursors
+        uint8_t *tables = nullptr;             // device: group_of_bin[bins] then RaggedGroupDev[groups]
+        unsigned *h_counts = nullptr;          // pinned: the histogram's way to the host
+        uint8_t *h_tables = nullptr;           // pinned: the tables' way to the device
+        hipEvent_t counted = nullptr;
+        const uint8_t *src_reads = nullptr, *src_refs = nullptr;      // of the chunk between begin and finish
+    };
+    static constexpr size_t kRaggedTableBytes = sizeof(uint16_t) * kRaggedMaxBins + sizeof(RaggedGroupDev) * kRaggedMaxGroups;
+
+    int ragged_bins() const { return (int)(read_caps_.size() * ref_caps_.size()); }
+    bool ragged_fits(long long n) const {
+        return ragged_bins() <= kRaggedMaxBins && read_caps_.size() * (size_t)kMaxScoreGroups <= (size_t)kRaggedMaxGroups &&
+               n < 0x7FFFFFFFll;
+    }
+
+    void ensure_ragged(int c, long long n) {
+        RaggedCtx &x = rag_[c];
+        if (!d_read_class_) {
+            hip_check(hipMalloc((void **)&d_read_class_, read_class_.size()), "hipMalloc(read classes)");
+            hip_check(hipMalloc((void **)&d_ref_class_, sizeof(uint16_t) * ref_class_.size()), "hipMalloc(ref classes)");
+            hip_check(hipMemcpy(d_read_class_, read_class_.data(), read_class_.size(), hipMemcpyHostToDevice), "hipMemcpy");
+            hip_check(hipMemcpy(d_ref_class_, ref_class_.data(), sizeof(uint16_t) * ref_class_.size(), hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        if (!x.counted) {
+            hip_check(hipEventCreateWithFlags(&x.counted, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipMalloc((void **)&x.counters, sizeof(unsigned) * (kRaggedMaxBins + kRaggedMaxGroups)), "hipMalloc(ragged counters)");
+            hip_check(hipMalloc((void **)&x.tables, kRaggedTableBytes), "hipMalloc(ragged tables)");
+            hip_check(hipHostMalloc((void **)&x.h_counts, sizeof(unsigned) * kRaggedMaxBins, hipHostMallocDefault), "hipHostMalloc");
+            hip_check(hipHostMalloc((void **)&x.h_tables, kRaggedTableBytes, hipHostMallocDefault), "hipHostMalloc");
+        }
+        if (x.cap >= n) return;
+        for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos})
+            if (p) (void)hipFree(p);                         // (hipFree waits for the device: nothing is still reading them)
+        x.reads = x.refs = nullptr;
+        x.scores = nullptr;
+        x.bin = nullptr;
+        x.pos = nullptr;
+        x.cap = 0;
+        hip_check(hipMalloc((void **)&x.reads, std::max<size_t>((size_t)n * R_, 16)), "hipMalloc(ragged reads)");
+        hip_check(hipMalloc((void **)&x.refs, std::max<size_t>((size_t)n * F_, 16)), "hipMalloc(ragged refs)");
+        hip_check(hipMalloc((void **)&x.scores, sizeof(int16_t) * (size_t)n), "hipMalloc(ragged scores)");
+        hip_check(hipMalloc((void **)&x.bin, sizeof(uint16_t) * (size_t)n), "hipMalloc(ragged bins)");
+        hip_check(hipMalloc((void **)&x.pos, sizeof(int) * (size_t)n), "hipMalloc(ragged places)");
+        x.cap = n;
+    }
+    void release_ragged() {
+        for (RaggedCtx &x : rag_) {
+            for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos, (void *)x.counters, (void *)x.tables})
+                if (p) (void)hipFree(p);
+            if (x.h_counts) (void)hipHostFree(x.h_counts);
+            if (x.h_tables) (void)hipHostFree(x.h_tables);
+            if (x.counted) (void)hipEventDestroy(x.counted);
+            x = RaggedCtx{};
+        }
+        if (d_read_class_) (void)hipFree(d_read_class_);
+        if (d_ref_class_) (void)hipFree(d_ref_class_);
+        d_read_class_ = nullptr;
+        d_ref_class_ = nullptr;
+    }
+
+    // first half: trimmed lengths -> bins, the histogram on its way to the host.  Asynchronous on `stream`.
+    void ragged_begin(int c, long long n, const uint8_t *d_reads, const uint8_t *d_refs, hipStream_t stream) {
+        ensure_ragged(c, n);
+        RaggedCtx &x = rag_[c];
+        x.src_reads = d_reads;
+        x.src_refs = d_refs;
+        const int NG = ragged_bins();
+        hip_check(hipMemsetAsync(x.counters, 0, sizeof(unsigned) * (kRaggedMaxBins + kRaggedMaxGroups), stream), "hipMemsetAsync");
+        RaggedClassifyArgs a{d_reads, d_refs, n, R_, F_, d_read_class_, d_ref_class_, (int)ref_caps_.size(), NG, x.bin, x.counters};
+        void *kargs[] = {&a};
+        const long long blocks = (n + kRaggedClassifyPairs - 1) / kRaggedClassifyPairs;
+        hip_check(hipLaunchKernel((const void *)&ragged_classify_kernel, dim3((unsigned)blocks), dim3(256), kargs, 0, stream),
+                  "hipLaunchKernel(ragged_classify_kernel)");
+        hip_check(hipMemcpyAsync(x.h_counts, x.counters, sizeof(unsigned) * (size_t)NG, hipMemcpyDeviceToHost, stream), "D2H histogram");
+        hip_check(hipEventRecord(x.counted, stream), "hipEventRecord");
+    }
+
+    // Fold bins too small to be worth a launch into the next larger one and lay the groups out: a read class with too few
+    // pairs for a launch of its own joins the next read class (bin by bin); inside a class, a reference bin smaller than a
+    // few blocks joins the next wider one.  Both dimensions only ever grow, so the padded sweep still covers the pair.
+    std::vector<LengthGroup> fold_groups(std::vector<long long> &total, std::vector<int> &group_of_bin) const {
         const int NR = (int)read_caps_.size(), NF = (int)ref_caps_.size(), NG = NR * NF;
-        const int R = R_, F = F_;
-        if (threads > 1 && cnt < 4096) threads = 1;
-        std::vector<unsigned short> &bin = bin_[slot];
-        std::vector<int> &pos = pos_[slot];
-        bin.resize((size_t)cnt);
-        pos.resize((size_t)cnt);
-        std::vector<long long> counts((size_t)threads * NG, 0);
-        const unsigned char *rclass = read_class_.data();
-        const unsigned short *fclass = ref_class_.data();
-        const auto t_begin = std::chrono::steady_clock::now();
-        for_ranges(threads, cnt, 4096, [&, rclass, fclass](int t, long long lo, long long hi) {
-            long long *mine = counts.data() + (size_t)t * NG;
-            for (long long i = lo; i < hi; ++i) {
-                if (i + 8 < hi) {                 // the tails are one cache miss each: keep several in flight
-                    __builtin_prefetch(reads[i + 8] + (R > 8 ? R - 8 : 0));
-                    __builtin_prefetch(refs[i + 8] + (F > 8 ? F - 8 : 0));
-                }
-                const int rc = rclass[trimmed_length((const unsigned char *)reads[i], R)];
-                const int fc = fclass[trimmed_length((const unsigned char *)refs[i], F)];
-                bin[(size_t)i] = (unsigned short)(rc * NF + fc);
-                mine[rc * NF + fc] += 1;
-            }
-        });
-        host_stats_.classify_ms += ms_between(t_begin, std::chrono::steady_clock::now());
-        // fold: a read class with too few pairs for a launch of its own joins the next read class
-        // (bin by bin); inside a class, a reference bin smaller than a few blocks joins the next
-        // wider one.  Both dimensions only ever grow, so the padded sweep still covers the pair.
-        std::vector<long long> total((size_t)NG, 0);
-        for (int t = 0; t < threads; ++t)
-            for (int g = 0; g < NG; ++g) total[g] += counts[(size_t)t * NG + g];
         std::vector<int> target((size_t)NG);
         for (int g = 0; g < NG; ++g) target[g] = g;
         const long long bin_min = std::min<long long>(ragged_min_, 256);
@@ -2034,7 +2090,7 @@ private:
         }
         for (int g = NG - 1; g >= 0; --g) target[g] = target[target[g]];      // targets only point forward
         std::vector<LengthGroup> groups;
-        std::vector<int> group_of((size_t)NG, -1);
+        std::vector<int> group_at((size_t)NG, -1);
         long long pair_ofs = 0;
         size_t read_ofs = 0, ref_ofs = 0;
         for (int g = 0; g < NG; ++g) {
@@ -2049,39 +2105,66 @@ private:
             pair_ofs += lg.pairs;
             read_ofs += (size_t)lg.pairs * lg.R;
             ref_ofs += (size_t)lg.pairs * lg.F;
-            group_of[g] = (int)groups.size();
+            group_at[g] = (int)groups.size();
             groups.push_back(lg);
         }
-        // first packed position of every (thread, group)
-        const int NL = (int)groups.size();
-        std::vector<long long> start((size_t)threads * NL, 0);
-        {
-            std::vector<long long> run((size_t)NL, 0);
-            for (int t = 0; t < threads; ++t) {
-                for (int l = 0; l < NL; ++l) start[(size_t)t * NL + l] = run[l];
-                for (int g = 0; g < NG; ++g)
-                    if (counts[(size_t)t * NG + g]) run[group_of[target[g]]] += counts[(size_t)t * NG + g];
-            }
-        }
-        uint8_t *dst_reads = h_reads_[slot], *dst_refs = h_refs_[slot];
-        const LengthGroup *gl = groups.data();
-        for_ranges(threads, cnt, 4096, [&, gl, dst_reads, dst_refs](int t, long long lo, long long hi) {
-            long long *next = start.data() + (size_t)t * NL;
-            for (long long i = lo; i < hi; ++i) {
-                if (i + 4 < hi) {
-                    __builtin_prefetch(reads[i + 4]);
-                    __builtin_prefetch(refs[i + 4]);
-                    __builtin_prefetch(refs[i + 4] + 64);
-                }
-                const int l = group_of[target[bin[(size_t)i]]];
-                const LengthGroup &g = gl[l];
-                const long long k = next[l]++;
-                pos[(size_t)i] = (int)(g.pair_ofs + k);
-                memcpy(dst_reads + g.read_ofs + (size_t)k * g.R, reads[i], (size_t)g.R);
-                memcpy(dst_refs + g.ref_ofs + (size_t)k * g.F, refs[i], (size_t)g.F);
-            }
-        });
+        group_of_bin.assign((size_t)NG, 0);
+        for (int g = 0; g < NG; ++g) group_of_bin[g] = std::max(group_at[target[g]], 0);     // (an empty bin: any group, no pair asks)
         return groups;
+    }
+
+    // second half: waits for the histogram, lays the groups out, then -- asynchronously on `stream` -- packs the pairs by
+    // group, sweeps class by class and puts the scores back in the caller's order.  `always` false: false is returned, and
+    // nothing launched, where the classes would still visit two thirds of the padded cells or more.
+    bool ragged_finish(int c, int alg, long long n, int16_t *d_scores, hipStream_t stream, bool always) {
+        RaggedCtx &x = rag_[c];
+        const int NG = ragged_bins();
+        const auto t0 = std::chrono::steady_clock::now();
+        hip_check(hipEventSynchronize(x.counted), "hipEventSynchronize");
+        host_stats_.classify_ms += ms_between(t0, std::chrono::steady_clock::now());
+        std::vector<long long> total((size_t)NG);
+        long long seen = 0;
+        for (int g = 0; g < NG; ++g) seen += (total[g] = (long long)x.h_counts[g]);
+        if (seen != n) throw std::runtime_error("length classification lost pairs");
+        std::vector<int> group_of_bin;
+        const std::vector<LengthGroup> groups = fold_groups(total, group_of_bin);
+        double swept = 0;
+        for (const LengthGroup &g : groups) swept += (double)g.pairs * g.R * g.F;
+        const double padded = (double)n * R_ * F_;
+        if (!always && swept >= 0.67 * padded) return false;
+        const int NL = (int)groups.size();
+        if (NL > kRaggedMaxGroups) throw std::runtime_error("too many length groups");
+        uint16_t *h_map = reinterpret_cast<uint16_t *>(x.h_tables);
+        RaggedGroupDev *h_groups = reinterpret_cast<RaggedGroupDev *>(x.h_tables + sizeof(uint16_t) * kRaggedMaxBins);
+        for (int g = 0; g < NG; ++g) h_map[g] = (uint16_t)group_of_bin[g];
+        for (int l = 0; l < NL; ++l)
+            h_groups[l] = RaggedGroupDev{groups[l].R, groups[l].F, groups[l].pair_ofs, (long long)groups[l].read_ofs, (long long)groups[l].ref_ofs};
+        hip_check(hipMemcpyAsync(x.tables, x.h_tables, kRaggedTableBytes, hipMemcpyHostToDevice, stream), "H2D length groups");
+        RaggedPermuteArgs pa{x.src_reads, x.src_refs, n, R_, F_, x.bin, reinterpret_cast<const uint16_t *>(x.tables),
+                             reinterpret_cast<const RaggedGroupDev *>(x.tables + sizeof(uint16_t) * kRaggedMaxBins), NL,
+                             x.counters + kRaggedMaxBins, x.reads, x.refs, x.pos};
+        void *pargs[] = {&pa};
+        hip_check(hipLaunchKernel((const void *)&ragged_place_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), pargs, 0, stream),
+                  "hipLaunchKernel(ragged_place_kernel)");
+        hip_check(hipLaunchKernel((const void *)&ragged_copy_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), pargs, 0, stream),
+                  "hipLaunchKernel(ragged_copy_kernel)");
+        // one launch per read class: its reference-length groups ride in the kernel's group table
+        for (size_t first = 0; first < groups.size();) {
+            size_t end = first;
+            int widest = 0;
+            while (end < groups.size() && groups[end].R == groups[first].R) widest = std::max(widest, groups[end++].F);
+            launch_score(class_plan(groups[first].R, widest), alg, groups[first].R, widest, 0, x.reads, x.refs, x.scores, stream,
+                         groups.data() + first, (int)(end - first));
+            host_stats_.launches += 1;
+            first = end;
+        }
+        RaggedUnpermuteArgs ua{x.scores, x.pos, d_scores, n};
+        void *uargs[] = {&ua};
+        hip_check(hipLaunchKernel((const void *)&ragged_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), uargs, 0, stream),
+                  "hipLaunchKernel(ragged_unpermute_kernel)");
+        host_stats_.cells_swept += swept;
+        host_stats_.cells_padded += padded;
+        return true;
     }
 
     void gather(const char *const *reads, const char *const *refs, long long cnt, uint8_t *dst_reads,
@@ -2103,10 +2186,10 @@ private:
     std::vector<unsigned char> read_class_;
     std::vector<unsigned short> ref_class_;
     std::map<std::pair<int, int>, LaunchPlan> class_plans_;
-    std::vector<unsigned short> bin_[kSlots];
-    std::vector<int> pos_[kSlots];
+    RaggedCtx rag_[kSlots];
+    uint8_t *d_read_class_ = nullptr;
+    uint16_t *d_ref_class_ = nullptr;
     HostPacker packer_{R_, F_};                               // (declared after R_ / F_)
-    bool slot_ragged_[kSlots] = {};
     HostStats host_stats_;
     bool no_sym_ = getenv("VALIGN_HIP_NO_SYM") != nullptr;   // tuning switch: use the two-gap kernel always
     bool no_tag_ = getenv("VALIGN_HIP_NO_TAG") != nullptr;   // tuning switch: equality-test pointer kernels for linear alignments

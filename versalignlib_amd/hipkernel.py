@@ -138,8 +138,8 @@ class Engine:
             raise HipKernelError(_err())
 
     def set_ragged_batching(self, mode):
-        """Length-sorted Smith-Waterman score batches on the host-pointer path: 0 never, 1 when the
-        call is ragged enough (default), 2 always."""
+        """Length-sorted score batches (classified, packed and swept by length class on the device; host-pointer calls
+        and score_device): 0 never (default), 1 when the call is ragged enough, 2 always."""
         if lib().valign_hip_set_ragged_batching(self._h, int(mode)) != 0:
             raise HipKernelError(_err())
 
