@@ -422,6 +422,42 @@ def reference_avx_sharded(reads, refs, procs, pairs_per_proc=32768):
                                            % (sample, procs, slowest)}
 
 
+def length_sorted_leg(reads, refs, scoring, device_index):
+    """The timed batch with every read and reference cut to a uniformly drawn prefix (10-100 %) and NUL-padded, as
+    pad() leaves a FASTA of mixed lengths (src/util/versalignUtil.cpp:17-33): swept padded and length-sorted."""
+    import torch
+    from versalignlib_amd import hipkernel
+    n = int(reads.shape[0])
+    g = torch.Generator(device=reads.device).manual_seed(77)
+    def cut(t):
+        L = t.shape[1]
+        keep = (torch.rand((n, 1), device=t.device, generator=g) * 0.9 * L + 0.1 * L).to(torch.int64) + 1
+        return torch.where(torch.arange(L, device=t.device)[None, :] < keep, t, torch.zeros((), dtype=t.dtype, device=t.device)).contiguous()
+    r2, f2 = cut(reads), cut(refs)
+    eng = hipkernel.Engine(int(reads.shape[1]), int(refs.shape[1]), scoring, device=device_index)
+    out = {}
+    scores = {}
+    for mode in (0, 2):
+        eng.set_ragged_batching(mode)
+        scores[mode] = eng.score_device(0, r2, f2)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eng.score_device(0, r2, f2, scores[mode])
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        d = eng.describe(0, n)
+        out["padded_sweep" if mode == 0 else "length_sorted"] = {
+            "ms": round(best * 1e3, 3), "gcups_on_padded_shape": round(n * reads.shape[1] * refs.shape[1] / best / 1e9, 1),
+            "launches": d.get("ragged_launches"), "cell_fraction": d.get("ragged_cell_fraction")}
+    out["identical_to_padded_sweep"] = bool(torch.equal(scores[0], scores[2]))
+    out["note"] = ("valign_hip_score_device, wall time of the call (mode 2 waits for the device's length histogram); the engine's own cell "
+                   "choice (half floats for this scoring); never part of `value`")
+    eng.close()
+    return out
+
+
 def abi_leg(reads, refs, threads, devices=1):
     """PCIe-inclusive figures through the plugin ABI, exactly as a versalignLib host drives a backend:
     dlopen + set_parameters + set_logger + spawn_alignment_kernel, then the two virtuals on scattered
@@ -762,6 +798,14 @@ def main(argv=None):
             except hipkernel.HipKernelError as e:
                 line["alignments"] = {"error": str(e)[:200]}
             eng_lin.close()
+            # a mixed-length batch of the same size, classified, packed and swept by length class on
+            # the device (ragged_batching = 2) against the padded sweep of the same bytes -- identical scores required
+            try:
+                line["length_sorted"] = length_sorted_leg(reads, refs, affine_sc, local_rank)
+                if not line["length_sorted"]["identical_to_padded_sweep"]:
+                    rc = 4
+            except hipkernel.HipKernelError as e:
+                line["length_sorted"] = {"error": str(e)[:200]}
             if not args.no_abi:
                 try:
                     threads = args.abi_threads or min(16, host_cores())
