@@ -5,6 +5,8 @@
 #include <thread>
 #include <vector>
 #include <malloc.h>
+#include <stdint.h>
+#include <sys/mman.h>
 struct A { char *read, *ref; short a,b,c,d; };
 int main(int argc, char **argv) {
     const long n = atol(argv[1]); const int T = atoi(argv[2]); const int mode = atoi(argv[3]); const int reps = argc > 4 ? atoi(argv[4]) : 3;
@@ -25,6 +27,14 @@ int main(int argc, char **argv) {
             } else if (mode == 2) {   // allocate all first, then copy
                 for (long i = lo; i < hi; ++i) { al[i].read = new char[AL]; al[i].ref = new char[AL]; }
                 for (long i = lo; i < hi; ++i) { memcpy(al[i].read, &src[(i % 4096) * 2 * AL], AL); memcpy(al[i].ref, &src[(i % 4096) * 2 * AL + AL], AL); }
+            } else if (mode == 4) {   // transparent huge pages for the arena the rows come from (glibc: 64 MB heaps, aligned)
+                uintptr_t heap = 0;
+                for (long i = lo; i < hi; ++i) {
+                    al[i].read = new char[AL]; al[i].ref = new char[AL];
+                    const uintptr_t h = (uintptr_t)al[i].ref >> 26;
+                    if (h != heap) { heap = h; madvise((void *)(h << 26), 64u << 20, MADV_HUGEPAGE); }
+                    memcpy(al[i].read, &src[(i % 4096) * 2 * AL], AL); memcpy(al[i].ref, &src[(i % 4096) * 2 * AL + AL], AL);
+                }
             } else {
                 for (long i = lo; i < hi; ++i) {
                     al[i].read = new char[AL]; al[i].ref = new char[AL];
