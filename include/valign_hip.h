@@ -31,10 +31,10 @@
  *                                                         (process-wide!): 2 (default) mallopt(M_TOP_PAD, 256 MB)
  *                                                         -- arenas grow in 256 MB steps, which takes the 2n
  *                                                         operator new[] result rows of a million-pair
- *                                                         compute_alignments call from ~700 ms to ~50 ms,
- *                                                         and madvise(MADV_HUGEPAGE) on the 64 MB heap windows
- *                                                         those rows come from (first-touch faults: 46 -> 38 ms);
- *                                                         1 also M_TRIM_THRESHOLD off; 0 touches nothing.
+ *                                                         compute_alignments call from ~700 ms to ~50 ms;
+ *                                                         1 also M_TRIM_THRESHOLD off; 3 = 2 + madvise(MADV_HUGEPAGE)
+ *                                                         on the untouched heap above fresh result rows (first-touch
+ *                                                         faults: 46 -> 38 ms, opt-in); 0 touches nothing.
  *                                                         Logged at WARNING level the first time
  *       host_packing .................................... score_alignments: 1 (default) sequences cross PCIe as 4-bit
  *                                                         base classes (identical scores), 0 raw ASCII

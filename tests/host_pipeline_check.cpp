@@ -59,14 +59,20 @@ void round_trip(int R, int F, long long n, int threads) {
                memcmp(st_refs.data() + (size_t)i * F, refs[(size_t)i], (size_t)F) == 0;
     expect(same, "gather " + std::to_string(R) + "x" + std::to_string(F) + " n=" + std::to_string(n) + " threads=" + std::to_string(threads));
 
-    // a fake device: rows = read bytes then ref bytes, idx = four values of the pair
+    // a fake device: rows = read bytes then ref bytes, idx = four values of the pair -- with what the kernels guarantee:
+    // both rows of a pair are zero in front of offset idx[0] (the strings are right-justified and start there)
     std::vector<uint8_t> st_rows((size_t)n * 2 * AL + 1);
     std::vector<short> st_idx((size_t)n * 4 + 1);
     for (long long i = 0; i < n; ++i) {
-        memcpy(st_rows.data() + (size_t)i * 2 * AL, st_reads.data() + (size_t)i * R, (size_t)R);
-        memcpy(st_rows.data() + (size_t)i * 2 * AL + R, st_refs.data() + (size_t)i * F, (size_t)F);
-        memset(st_rows.data() + (size_t)i * 2 * AL + AL, (int)(i & 0xFF), AL);
-        for (int k = 0; k < 4; ++k) st_idx[(size_t)i * 4 + k] = (short)(i * 4 + k);
+        uint8_t *row = st_rows.data() + (size_t)i * 2 * AL;
+        memcpy(row, st_reads.data() + (size_t)i * R, (size_t)R);
+        memcpy(row + R, st_refs.data() + (size_t)i * F, (size_t)F);
+        memset(row + AL, (int)(i & 0xFF) | 1, AL);
+        const size_t start = AL ? (size_t)(mix((uint64_t)i + 99) % (AL + 1)) : 0;      // 0 .. AL (AL: an empty string)
+        memset(row, 0, start);
+        memset(row + AL, 0, start);
+        st_idx[(size_t)i * 4] = (short)start;
+        for (int k = 1; k < 4; ++k) st_idx[(size_t)i * 4 + k] = (short)(i * 4 + k);
     }
     std::vector<uint8_t> flat_rows((size_t)n * 2 * AL + 1, 0xEE);
     std::vector<short> flat_idx((size_t)n * 4 + 1, -1);
@@ -84,14 +90,16 @@ void round_trip(int R, int F, long long n, int threads) {
         packer.scatter(sink + k, n - k, st_rows.data() + (size_t)k * 2 * AL, st_idx.data() + 4 * k, threads);
         expect(memcmp(flat_rows.data(), st_rows.data(), (size_t)n * 2 * AL) == 0, "flat scatter in two chunks");
     }
-    {
+    for (int variant = 0; variant < 3; ++variant) {              // strings only / whole rows / with the huge-page hint for the rows' heap
+        packer.set_whole_rows(variant == 1);
+        packer.set_huge_rows(variant == 2);
         std::vector<FakeAlignment> out((size_t)n);
         packer.scatter(out.data(), n, st_rows.data(), st_idx.data(), threads);
         bool ok = true;
         for (long long i = 0; i < n && ok; ++i) {
             const FakeAlignment &a = out[(size_t)i];
             ok = a.read && a.ref && memcmp(a.read, st_rows.data() + (size_t)i * 2 * AL, AL) == 0 &&
-                 memcmp(a.ref, st_rows.data() + (size_t)i * 2 * AL + AL, AL) == 0 && a.readStart == (short)(i * 4) &&
+                 memcmp(a.ref, st_rows.data() + (size_t)i * 2 * AL + AL, AL) == 0 && a.readStart == st_idx[(size_t)i * 4] &&
                  a.readEnd == (short)(i * 4 + 1) && a.refStart == (short)(i * 4 + 2) && a.refEnd == (short)(i * 4 + 3);
         }
         expect(ok, "Alignment scatter n=" + std::to_string(n));

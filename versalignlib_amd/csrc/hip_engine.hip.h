@@ -468,8 +468,8 @@ public:
         // call then WAITS for the classification (the host lays the groups out); mode 1 sweeps the batch as it stands when
         // the length classes would not skip a third of the cells.
         if (length_sorted && ragged_applies(alg) && ragged_fits(n) && n >= 2 * ragged_min_) {
-            ragged_begin(0, n, d_reads, d_refs, stream);
-            if (ragged_finish(0, alg, n, d_scores, stream, ragged_ == 2)) return;
+            ragged_begin(kSlots, n, d_reads, d_refs, stream);           // (a context of its own: the pipeline's slots may be busy on the engine's streams)
+            if (ragged_finish(kSlots, alg, n, d_scores, stream, ragged_ == 2)) return;
         }
         // a batch that leaves most SIMDs with at most one wave is over when its slowest wave is: shortest sweep
         const bool few = n <= (long long)latency_plan_.pairs_per_wave * 1024 && band_width_ == 0;
@@ -1976,8 +1976,8 @@ private:
     }
 
     // ---- length-sorted batching on the device (ragged_kernels.hip.h) ----
-    // One context per pipeline slot (chunks of different slots are in flight side by side); context 0 also serves
-    // device-resident batches (score_device).
+    // One context per pipeline slot (chunks of different slots are in flight side by side) and one for device-resident
+    // batches (score_device, on the caller's stream).
     struct RaggedCtx {
         long long cap = 0;                     // pairs the buffers hold
         uint8_t *reads = nullptr, *refs = nullptr;     // the packed groups
@@ -2188,7 +2188,7 @@ private:
     std::vector<unsigned char> read_class_;
     std::vector<unsigned short> ref_class_;
     std::map<std::pair<int, int>, LaunchPlan> class_plans_;
-    RaggedCtx rag_[kSlots];
+    RaggedCtx rag_[kSlots + 1];                                  // one per pipeline slot, the last for device-resident batches
     uint8_t *d_read_class_ = nullptr;
     uint16_t *d_ref_class_ = nullptr;
     HostPacker packer_{R_, F_};                               // (declared after R_ / F_)

@@ -217,23 +217,27 @@ public:
             // glibc grows a thread arena in steps of M_TOP_PAD (128 KB by default), each one an mprotect() under the
             // process's mm lock: with 16 threads that is what the call costs (650-850 ms per million pairs, the bare
             // allocation loop without any plugin included -- tools/microbench/host_alloc.cpp).  256 MB steps make it
-            // 45-60 ms.  2 (default): M_TOP_PAD -- address space is reserved in larger steps, pages are still
-            // committed on first touch and returned on free -- and a huge-page hint for the rows' arena windows; 1: also never trim (the host keeps freed rows for the next
+            // 45-60 ms.  2 (default): M_TOP_PAD only -- address space is reserved in larger steps, pages are still
+            // committed on first touch and returned on free; 1: also never trim (the host keeps freed rows for the next
             // call: the recycled case without relying on glibc's dynamic threshold); 0: leave the host's allocator alone.
             const int tuning = opt_param("host_malloc_tuning", 2);
             if (tuning == 1) mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
-            if (tuning == 1 || tuning == 2) {
-                mallopt(M_TOP_PAD, 256 << 20);
-                // ... and the 64 MB windows of the arenas the rows come out of are recommended for transparent huge pages
-                // (madvise; 350,000 first-touch faults per million pairs become 700 where the system's setting is `madvise`)
+            if (tuning == 3) {
+                // 3 = 2 + the untouched top of the heap the result rows come out of is recommended for transparent huge pages
+                // (madvise; 350,000 first-touch faults per million pairs become 700 where the system's setting is `madvise`).
+                // Opt-in: the hint stays on that part of the host's heap after the rows are gone.
                 engine_->set_huge_rows(true);
                 for (auto &e : more_) e->set_huge_rows(true);
+            }
+            if (tuning >= 1 && tuning <= 3) {
+                mallopt(M_TOP_PAD, 256 << 20);
+
                 // a process-wide setting of the HOST's allocator: said out loud (WARNING level) the first time
                 static std::atomic<bool> told{false};
                 log_line(told.exchange(true) ? 0 : 1, std::string("host_malloc_tuning = ") + std::to_string(tuning) +
                                 ": mallopt(M_TOP_PAD, 256 MB)" + (tuning == 1 ? " + M_TRIM_THRESHOLD off" : "") +
-                                " + madvise(MADV_HUGEPAGE) on the arena windows the result rows of compute_alignments come from "
-                                "(0 leaves the host's allocator alone)");
+                                (tuning == 3 ? " + madvise(MADV_HUGEPAGE) on the untouched heap above fresh result rows" : "") +
+                                " for the result rows of compute_alignments (0 leaves the host's allocator alone)");
             }
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();
