@@ -341,6 +341,7 @@ public:
         double cells_swept = 0, cells_padded = 0;
         double gather_ms = 0, wait_ms = 0, drain_ms = 0;     // host time: packing, blocked on the device, copy-out
         double classify_ms = 0;                              // length-sorted batching: host time spent waiting for the device's histograms
+        double launch_ms = 0;                                // ... and laying the groups out + launching their sweeps
         int packed = 0;                                      // 1: the sequences crossed PCIe as 4-bit classes
         int direct_out = 0;                                  // 1: results were copied straight into the caller's (registered) buffers
         int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly; 2: ... in one fused launch
@@ -944,8 +945,13 @@ public:
                 hip_check(hipMemcpyAsync(h_scores_[s], d_scores_[s], sizeof(short) * (size_t)pairs, hipMemcpyDeviceToHost, cs), "D2H scores");
             hip_check(hipEventRecord(slot_done_[s], cs), "hipEventRecord");
         };
-        int open_slot = -1;                        // the length-sorted chunk whose sweeps are not launched yet
-        long long open_pairs = 0;
+        // (two iterations late, in fact: one gather is about as long as a chunk's copy + classification, two leave room)
+        struct OpenChunk {
+            int slot;
+            long long pairs;
+        };
+        std::vector<OpenChunk> open;               // length-sorted chunks whose sweeps are not launched yet, oldest first
+        constexpr size_t kOpenChunks = 2;          // (< kSlots - 1: a slot comes round again only after its chunk is finished)
         int slot = 0;
         // Ramp: the device idles until the first chunk is gathered and copied, so the first chunks are short (a quarter,
         // then half a chunk); chunks of many calls deep in the pipeline stay large (fewer launches, full waves).
@@ -984,14 +990,16 @@ public:
                 finish_chunk(slot, cnt);
             } else {
                 ragged_begin(slot, cnt, d_reads_[slot], d_refs_[slot], st);
-                if (open_slot >= 0) finish_chunk(open_slot, open_pairs);
-                open_slot = slot;
-                open_pairs = cnt;
+                open.push_back(OpenChunk{slot, cnt});
+                if (open.size() > kOpenChunks) {
+                    finish_chunk(open.front().slot, open.front().pairs);
+                    open.erase(open.begin());
+                }
             }
             slot_begin_[slot] = begin;
             slot_pending_[slot] = cnt;
         }
-        if (open_slot >= 0) finish_chunk(open_slot, open_pairs);
+        for (const OpenChunk &c : open) finish_chunk(c.slot, c.pairs);
         for (int k = 0; k < kSlots; ++k) {          // oldest chunk first
             const int s = (slot + k) % kSlots;
             auto t0 = std::chrono::steady_clock::now();
@@ -1578,8 +1586,8 @@ public:
     // host-side phases of the last score_host / align_host call
     std::string host_phases() const {
         char buf[200];
-        snprintf(buf, sizeof buf, "{\"host_gather_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
-                 host_stats_.gather_ms, host_stats_.wait_ms, host_stats_.drain_ms);
+        snprintf(buf, sizeof buf, "{\"host_gather_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_launch_ms\": %.3f}",
+                 host_stats_.gather_ms, host_stats_.wait_ms, host_stats_.drain_ms, host_stats_.classify_ms, host_stats_.launch_ms);
         return buf;
     }
 
@@ -2123,7 +2131,8 @@ private:
         const int NG = ragged_bins();
         const auto t0 = std::chrono::steady_clock::now();
         hip_check(hipEventSynchronize(x.counted), "hipEventSynchronize");
-        host_stats_.classify_ms += ms_between(t0, std::chrono::steady_clock::now());
+        const auto t_counted = std::chrono::steady_clock::now();
+        host_stats_.classify_ms += ms_between(t0, t_counted);
         std::vector<long long> total((size_t)NG);
         long long seen = 0;
         for (int g = 0; g < NG; ++g) seen += (total[g] = (long long)x.h_counts[g]);
@@ -2166,6 +2175,7 @@ private:
                   "hipLaunchKernel(ragged_unpermute_kernel)");
         host_stats_.cells_swept += swept;
         host_stats_.cells_padded += padded;
+        host_stats_.launch_ms += ms_between(t_counted, std::chrono::steady_clock::now());
         return true;
     }
 
