@@ -458,7 +458,54 @@ def length_sorted_leg(reads, refs, scoring, device_index):
     return out
 
 
-def abi_leg(reads, refs, threads, devices=1):
+def in_plugin_shards_child(devices, threads):
+    """`bench.py --child-in-plugin-shards N` in a process of its own; its JSON line, or what became of it."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                        "TORCHELASTIC_RUN_ID", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--child-in-plugin-shards", str(devices), "--abi-threads", str(threads)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out after 300 s", "devices": devices}
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": "child exit code %d" % r.returncode, "stderr_tail": r.stderr[-400:], "devices": devices}
+
+
+def child_in_plugin_shards(devices, threads):
+    """The child: synthetic host sequences (no torch, no rank), the plugin with hip_devices = N: score_alignments with the
+    host-side merge of the shards and with the in-plugin RCCL all-gather, checked against each other and against one device."""
+    from versalignlib_amd import build, host, synth
+    import numpy as np
+    blk = 1 << 16
+    r0, f0 = synth.make_pairs(blk, R, F, seed=2000)
+    h_reads, h_refs = np.tile(r0, (PAIRS_PER_GPU // blk, 1)), np.tile(f0, (PAIRS_PER_GPU // blk, 1))
+    n = int(h_reads.shape[0])
+    keys = dict(score_gap_open_read=AFFINE["open_read"], score_gap_extend_read=AFFINE["ext_read"],
+                score_gap_open_ref=AFFINE["open_ref"], score_gap_extend_ref=AFFINE["ext_ref"])
+    out = {"devices": devices, "threads": threads, "pairs": n}
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k1:
+        one = k1.score_alignments(0, h_reads, h_refs, scattered=True)[0].copy()
+    for name, extra in (("score_alignments_sw", {}), ("score_alignments_sw_rccl_allgather", {"hip_devices_allgather": 1})):
+        try:
+            with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, hip_devices=devices, hip_devices_strict=1, **extra, **keys) as k:
+                k.score_alignments(0, h_reads, h_refs, scattered=True)
+                runs = [k.score_alignments(0, h_reads, h_refs, scattered=True) for _ in range(4)]
+                best = min(r[1] for r in runs)
+                out[name] = {"ms": round(best * 1e3, 2), "gcups": round(n * R * F / best / 1e9, 1),
+                             "identical_to_one_device": bool(np.array_equal(runs[-1][0], one))}
+        except Exception as e:
+            out[name] = {"error": str(e)[:300]}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def abi_leg(reads, refs, threads):
     """PCIe-inclusive figures through the plugin ABI, exactly as a versalignLib host drives a backend:
     dlopen + set_parameters + set_logger + spawn_alignment_kernel, then the two virtuals on scattered
     heap blocks (pad(), src/util/versalignUtil.cpp:24-31).  Affine scoring as in `value`.  Warm: the first
@@ -466,19 +513,16 @@ def abi_leg(reads, refs, threads, devices=1):
     import numpy as np
     from versalignlib_amd import build, host, synth
     n = int(reads.shape[0])
-    h_reads, h_refs = reads.cpu().numpy(), refs.cpu().numpy()
+    h_reads, h_refs = (reads.cpu().numpy(), refs.cpu().numpy()) if hasattr(reads, "cpu") else (reads, refs)
     keys = dict(score_gap_open_read=AFFINE["open_read"], score_gap_extend_read=AFFINE["ext_read"],
                 score_gap_open_ref=AFFINE["open_ref"], score_gap_extend_ref=AFFINE["ext_ref"])
     out = {"threads": threads, "pairs": n, "note": "through spawn_alignment_kernel with one heap block per sequence; "
                                                     "PCIe and host gather/scatter included; never part of `value`"}
-    if devices > 1:
-        keys["hip_devices"] = devices
-        out["hip_devices"] = devices
     # compute_alignments(SW) hands out 2n operator new[] rows per call (include/AlignmentKernel.h:20-23).  What that costs
     # is glibc's arena growth: 128 KB steps (an mprotect each, 16 threads contending) by default, 256 MB steps with the
     # plugin's default host_malloc_tuning = 2 (mallopt(M_TOP_PAD), process-wide and sticky: the untuned figures first).
     untuned = None
-    if devices <= 1:            # (the first abi_leg of the process: no plugin object has changed the allocator yet)
+    if True:                    # (the first plugin object of the process: nothing has changed the allocator yet)
         with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=0, **keys) as k:
             floor_untuned, _ = host.alloc_probe(n, R + F, threads)
             k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
@@ -494,15 +538,6 @@ def abi_leg(reads, refs, threads, devices=1):
                                       "gcups": round(n * R * F / secs[0] / 1e9, 1),
                                       "transport": "4-bit base classes (host_packing = 1, default)",
                                       "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
-    if devices > 1:
-        # the same call with the per-shard scores all-gathered by RCCL inside the plugin (hip_devices_allgather = 1)
-        try:
-            with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, hip_devices_allgather=1, hip_devices_strict=1, **keys) as kg:
-                kg.score_alignments(0, h_reads, h_refs, scattered=True)
-                secs = sorted(kg.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(3))
-                out["score_alignments_sw_rccl_allgather"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1)}
-        except Exception as e:
-            out["score_alignments_sw_rccl_allgather"] = {"error": str(e)[:200]}
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_packing=0, **keys) as k0:
         k0.score_alignments(0, h_reads, h_refs, scattered=True)
         secs = sorted(k0.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(4))
@@ -625,10 +660,13 @@ def main(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-abi", action="store_true", help="skip the plugin-ABI (PCIe-inclusive) leg")
     ap.add_argument("--abi-threads", type=int, default=0, help="num_threads of the ABI leg (default: host cores, <= 16)")
+    ap.add_argument("--child-in-plugin-shards", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU/gloo self-test of launcher + all-gather + result relay; computes no alignment")
     args = ap.parse_args(argv)
 
+    if args.child_in_plugin_shards:
+        return child_in_plugin_shards(args.child_in_plugin_shards, args.abi_threads or 16)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -813,13 +851,15 @@ def main(argv=None):
                     # the plugin picks the half-float-cell kernel for this scoring: that is the kernel the call contains
                     for key in ("score_alignments_sw", "score_alignments_sw_ascii"):
                         line["abi"][key]["ratio_to_kernel_ms"] = round(line["abi"][key]["ms"] / line["half_float"]["kernel_ms"], 3)
-                    visible = torch.cuda.device_count()
-                    if world > 1 and visible > 1:
-                        # one host process driving several devices through the plugin key hip_devices, on the
-                        # real devices of this node (the other ranks wait on the host, their GPUs are idle)
-                        line["abi_in_plugin_shards"] = abi_leg(reads, refs, threads, devices=min(world, visible))
                 except Exception as e:
                     line["abi"] = {"error": str(e)[:300]}
+                visible = torch.cuda.device_count()
+                if world > 1 and visible > 1:
+                    # one host process driving several devices through the plugin key hip_devices (and the RCCL all-gather
+                    # inside the plugin), on the real devices of this node while the other ranks wait on the host.  In a
+                    # CHILD process: this path has never met more than one real device, and whatever it does there must
+                    # not take the rank that prints the line with it.
+                    line["abi_in_plugin_shards"] = in_plugin_shards_child(min(world, visible), args.abi_threads or min(16, host_cores()))
         oracle_scores = None
         if world == 1 and not args.no_cpu:
             if long_mode:
