@@ -47,3 +47,17 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"], env=env,
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_in_plugin_shards_child_cannot_take_the_rank_down():
+    """The in-plugin multi-device leg of an N > 1 run is a child process of rank 0: whatever becomes of it -- here, on a
+    machine without a GPU, the plugin refuses to spawn a kernel -- the parent gets a dict to put in its line."""
+    if os.path.exists("/dev/kfd"):
+        import pytest
+        pytest.skip("a GPU is present")
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.in_plugin_shards_child(2, 2)
+    assert isinstance(out, dict) and out.get("devices") == 2
+    legs = [out.get("score_alignments_sw"), out.get("score_alignments_sw_rccl_allgather")]
+    assert "error" in out or all(isinstance(x, dict) and "error" in x for x in legs), out
