@@ -458,23 +458,62 @@ def length_sorted_leg(reads, refs, scoring, device_index):
     return out
 
 
-def in_plugin_shards_child(devices, threads):
-    """`bench.py --child-in-plugin-shards N` in a process of its own; its JSON line, or what became of it."""
-    env = {k: v for k, v in os.environ.items()
-           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
-                        "TORCHELASTIC_RUN_ID", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
-    cmd = [sys.executable, os.path.abspath(__file__), "--child-in-plugin-shards", str(devices), "--abi-threads", str(threads)]
+def run_child_leg(flags, keep_devices=False):
+    """A leg of the bench in a process of its own (`bench.py --child-...`): its JSON line, or what became of it."""
+    drop = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"]
+    if not keep_devices:
+        drop += ["HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"]
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    cmd = [sys.executable, os.path.abspath(__file__)] + [str(f) for f in flags]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
     except subprocess.TimeoutExpired:
-        return {"error": "child timed out after 300 s", "devices": devices}
+        return {"error": "child timed out after 300 s"}
     for ln in reversed(r.stdout.strip().splitlines()):
         if ln.startswith("{"):
             try:
                 return json.loads(ln)
             except ValueError:
                 break
-    return {"error": "child exit code %d" % r.returncode, "stderr_tail": r.stderr[-400:], "devices": devices}
+    return {"error": "child exit code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+
+
+def in_plugin_shards_child(devices, threads):
+    out = run_child_leg(["--child-in-plugin-shards", devices, "--abi-threads", threads])
+    out.setdefault("devices", devices)
+    return out
+
+
+def child_huge_rows(threads, device):
+    """The child: compute_alignments(SW) through the ABI with host_malloc_tuning = 3 (the untouched heap above fresh result
+    rows recommended for transparent huge pages) -- fresh rows (earlier results alive) and recycled rows, as in abi_leg."""
+    from versalignlib_amd import build, host, synth
+    import numpy as np
+    blk = 1 << 16
+    r0, f0 = synth.make_pairs(blk, R, F, seed=2000)
+    h_reads, h_refs = np.tile(r0, (PAIRS_PER_GPU // blk, 1)), np.tile(f0, (PAIRS_PER_GPU // blk, 1))
+    n = int(h_reads.shape[0])
+    keys = dict(score_gap_open_read=AFFINE["open_read"], score_gap_extend_read=AFFINE["ext_read"],
+                score_gap_open_ref=AFFINE["open_ref"], score_gap_extend_ref=AFFINE["ext_ref"])
+    if device:
+        keys["hip_device"] = device
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=3, **keys) as k:
+        k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
+        _, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=False)
+        phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
+        out = {"ms_fresh_rows": round(min(per_call[1:]) * 1e3, 2),
+               "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
+        _, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=True)
+        out["ms_recycled_rows"] = round(min(per_call[1:]) * 1e3, 2)
+    try:
+        with open("/sys/kernel/mm/transparent_hugepage/enabled") as f:
+            out["transparent_hugepage"] = f.read().strip()
+    except OSError:
+        pass
+    out["note"] = ("host_malloc_tuning = 3 (opt-in): madvise(MADV_HUGEPAGE) on the untouched heap above fresh result rows; measured in a "
+                   "child process of the bench")
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def child_in_plugin_shards(devices, threads):
@@ -661,12 +700,15 @@ def main(argv=None):
     ap.add_argument("--no-abi", action="store_true", help="skip the plugin-ABI (PCIe-inclusive) leg")
     ap.add_argument("--abi-threads", type=int, default=0, help="num_threads of the ABI leg (default: host cores, <= 16)")
     ap.add_argument("--child-in-plugin-shards", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-huge-rows", type=int, default=-1, help=argparse.SUPPRESS)     # value: the device
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU/gloo self-test of launcher + all-gather + result relay; computes no alignment")
     args = ap.parse_args(argv)
 
     if args.child_in_plugin_shards:
         return child_in_plugin_shards(args.child_in_plugin_shards, args.abi_threads or 16)
+    if args.child_huge_rows >= 0:
+        return child_huge_rows(args.abi_threads or 16, args.child_huge_rows)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -851,6 +893,9 @@ def main(argv=None):
                     # the plugin picks the half-float-cell kernel for this scoring: that is the kernel the call contains
                     for key in ("score_alignments_sw", "score_alignments_sw_ascii"):
                         line["abi"][key]["ratio_to_kernel_ms"] = round(line["abi"][key]["ms"] / line["half_float"]["kernel_ms"], 3)
+                    # ... and the fresh-row call with the opt-in huge-page hint, in a child process
+                    line["abi"]["compute_alignments_sw"]["host_malloc_tuning_3"] = run_child_leg(
+                        ["--child-huge-rows", local_rank, "--abi-threads", threads], keep_devices=True)
                 except Exception as e:
                     line["abi"] = {"error": str(e)[:300]}
                 visible = torch.cuda.device_count()
