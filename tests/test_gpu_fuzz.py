@@ -2,7 +2,7 @@
 libHIPKernel.so against the oracle, bit-exact, for combinations no hand-written case names (zero and
 equal gap scores, zero mismatch, large matches, tiny and lopsided shapes, every affine variant, both
 traceback policies).  Deterministic: the configurations come from splitmix64.  700 configurations by
-default; VALIGN_FUZZ_CASES=N runs the first N (soaked with 4000 in both rounds; round 2's soak found case 604 --
+default; VALIGN_FUZZ_CASES=N runs the first N (soaked with 4000 in every round; round 2's soak found case 604 --
 a half-float NW score above 2048 -- which is why the default run reaches past it)."""
 import numpy as np
 import pytest
