@@ -27,5 +27,14 @@ for it in range(40):
     e.score_device((it + 1) % 2, reads[:m], refs[:m])
 f1 = free()
 print("free before %.1f MB, after %.1f MB, delta %.1f MB" % (f0 / 2**20, f1 / 2**20, (f0 - f1) / 2**20))
+# length-sorted batching on the device: its contexts (packed copies, bins, places) are per engine and persistent too
+eng.set_ragged_batching(2)
+eng.score_device(0, reads, refs); eng.score_device(1, reads[: n // 2], refs[: n // 2])
+f_r0 = free()
+for it in range(10):
+    eng.score_device(it % 2, reads[: n - 1000 * it], refs[: n - 1000 * it])
+f_r1 = free()
+print("length-sorted calls: free before %.1f MB, after %.1f MB, delta %.1f MB" % (f_r0 / 2**20, f_r1 / 2**20, (f_r0 - f_r1) / 2**20))
+eng.set_ragged_batching(0)
 eng.close(); lin.close()
 print("after close free %.1f MB" % (free() / 2**20))
