@@ -77,7 +77,7 @@ struct ScoreArgs {
     short match, mismatch;
     short gap_read, gap_ref;                       // linear model, all <= 0
     short open_read, ext_read, open_ref, ext_ref;  // affine extension, all <= 0
-    // Length-sorted batches (hip_engine.hip.h, gather_ragged): one launch sweeps several packed groups
+    // Length-sorted batches (ragged_kernels.hip.h; Engine::ragged_finish): one launch sweeps several packed groups
     // of pairs that share the read stride R but have their own reference stride.  Blocks
     // [groups[g-1].block_end, groups[g].block_end) belong to group g; reads / refs / scores / n / F
     // above are then ignored in favour of the group's.  n_groups == 0: one plain batch.

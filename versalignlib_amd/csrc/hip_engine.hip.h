@@ -1992,6 +1992,7 @@ private:
         int16_t *scores = nullptr;             // ... and their scores, packed order
         uint16_t *bin = nullptr;               // length bin of every pair
         int *pos = nullptr;                    // packed place of every pair
+        RaggedPlace *place = nullptr;          // ... as byte offsets + strides, for the copy kernel
         unsigned *counters = nullptr;          // bins' pair counts, then the groups' fill cursors
         uint8_t *tables = nullptr;             // device: group_of_bin[bins] then RaggedGroupDev[groups]
         unsigned *h_counts = nullptr;          // pinned: the histogram's way to the host
@@ -2023,23 +2024,25 @@ private:
             hip_check(hipHostMalloc((void **)&x.h_tables, kRaggedTableBytes, hipHostMallocDefault), "hipHostMalloc");
         }
         if (x.cap >= n) return;
-        for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos})
+        for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos, (void *)x.place})
             if (p) (void)hipFree(p);                         // (hipFree waits for the device: nothing is still reading them)
         x.reads = x.refs = nullptr;
         x.scores = nullptr;
         x.bin = nullptr;
         x.pos = nullptr;
+        x.place = nullptr;
         x.cap = 0;
         hip_check(hipMalloc((void **)&x.reads, std::max<size_t>((size_t)n * R_, 16)), "hipMalloc(ragged reads)");
         hip_check(hipMalloc((void **)&x.refs, std::max<size_t>((size_t)n * F_, 16)), "hipMalloc(ragged refs)");
         hip_check(hipMalloc((void **)&x.scores, sizeof(int16_t) * (size_t)n), "hipMalloc(ragged scores)");
         hip_check(hipMalloc((void **)&x.bin, sizeof(uint16_t) * (size_t)n), "hipMalloc(ragged bins)");
         hip_check(hipMalloc((void **)&x.pos, sizeof(int) * (size_t)n), "hipMalloc(ragged places)");
+        hip_check(hipMalloc((void **)&x.place, sizeof(RaggedPlace) * (size_t)n), "hipMalloc(ragged place records)");
         x.cap = n;
     }
     void release_ragged() {
         for (RaggedCtx &x : rag_) {
-            for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos, (void *)x.counters, (void *)x.tables})
+            for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos, (void *)x.place, (void *)x.counters, (void *)x.tables})
                 if (p) (void)hipFree(p);
             if (x.h_counts) (void)hipHostFree(x.h_counts);
             if (x.h_tables) (void)hipHostFree(x.h_tables);
@@ -2153,7 +2156,7 @@ private:
         hip_check(hipMemcpyAsync(x.tables, x.h_tables, kRaggedTableBytes, hipMemcpyHostToDevice, stream), "H2D length groups");
         RaggedPermuteArgs pa{x.src_reads, x.src_refs, n, R_, F_, x.bin, reinterpret_cast<const uint16_t *>(x.tables),
                              reinterpret_cast<const RaggedGroupDev *>(x.tables + sizeof(uint16_t) * kRaggedMaxBins), NL,
-                             x.counters + kRaggedMaxBins, x.reads, x.refs, x.pos};
+                             x.counters + kRaggedMaxBins, x.reads, x.refs, x.pos, x.place};
         void *pargs[] = {&pa};
         hip_check(hipLaunchKernel((const void *)&ragged_place_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), pargs, 0, stream),
                   "hipLaunchKernel(ragged_place_kernel)");

@@ -41,6 +41,11 @@ struct RaggedClassifyArgs {
     unsigned *counts;                 // NG, zeroed
 };
 
+struct RaggedPlace {          // where a pair goes: byte offsets into the packed buffers and its group's strides
+    long long read_at, ref_at;
+    int R, F;
+};
+
 struct RaggedPermuteArgs {
     const uint8_t *reads, *refs;
     long long n;
@@ -52,6 +57,7 @@ struct RaggedPermuteArgs {
     unsigned *cursors;                // NL, zeroed: pairs placed so far per group
     uint8_t *out_reads, *out_refs;
     int *pos;                         // n: place of pair i in the packed order (the group's pair_ofs + its rank)
+    RaggedPlace *place;               // n: the same as byte offsets, for the copy
 };
 
 struct RaggedUnpermuteArgs {
@@ -172,11 +178,16 @@ __global__ void __launch_bounds__(256) ragged_place_kernel(const RaggedPermuteAr
     for (int k = t; k < a.NL; k += 256)
         if (cnt[k]) base[k] = atomicAdd(&a.cursors[k], cnt[k]);
     __syncthreads();
-    if (i < a.n) a.pos[i] = (int)(a.groups[g].pair_ofs + (long long)(base[g] + rank));
+    if (i < a.n) {
+        const RaggedGroupDev grp = a.groups[g];
+        const long long place = (long long)(base[g] + rank);
+        a.pos[i] = (int)(grp.pair_ofs + place);
+        a.place[i] = RaggedPlace{grp.read_ofs + place * grp.R, grp.ref_ofs + place * grp.F, grp.R, grp.F};
+    }
 }
 
-// ... and the copy: a wave per pair, a dword per lane (source and destination at any alignment), every load of the pair in
-// flight before the first store
+// ... and the copy: a wave per pair (its place record first: one load, wave-uniform), a dword per lane (source and
+// destination at any alignment), every load of the pair in flight before the first store
 constexpr int kRaggedCopyRounds = 3;          // 768 bytes per sequence without a loop
 __device__ __forceinline__ void ragged_copy_row(uint8_t *dst, const uint8_t *src, int len, int lane) {
     const int body = len & ~3;
@@ -203,11 +214,9 @@ __global__ void __launch_bounds__(256) ragged_copy_kernel(const RaggedPermuteArg
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.n) return;                                                     // (wave-uniform)
-    const unsigned g = a.group_of_bin[a.bin[i]];
-    const RaggedGroupDev grp = a.groups[g];
-    const long long place = (long long)a.pos[i] - grp.pair_ofs;
-    ragged_copy_row(a.out_reads + grp.read_ofs + place * grp.R, a.reads + i * a.R, grp.R, lane);
-    ragged_copy_row(a.out_refs + grp.ref_ofs + place * grp.F, a.refs + i * a.F, grp.F, lane);
+    const RaggedPlace p = a.place[i];                                         // one record, then the rows: no chain of table lookups
+    ragged_copy_row(a.out_reads + p.read_at, a.reads + i * a.R, p.R, lane);
+    ragged_copy_row(a.out_refs + p.ref_at, a.refs + i * a.F, p.F, lane);
 }
 
 __global__ void __launch_bounds__(256) ragged_unpermute_kernel(const RaggedUnpermuteArgs a) {
