@@ -27,15 +27,14 @@
  *                                                         (trailing non-ACGT padding is not swept,
  *                                                         identical scores): 0 never (default), 1 when a
  *                                                         sample of the call is ragged enough, 2 always
- *       host_malloc_tuning .............................. what spawning a kernel does to the HOST's allocator
- *                                                         (process-wide!): 2 (default) mallopt(M_TOP_PAD, 256 MB)
- *                                                         -- arenas grow in 256 MB steps, which takes the 2n
- *                                                         operator new[] result rows of a million-pair
- *                                                         compute_alignments call from ~700 ms to ~50 ms;
- *                                                         1 also M_TRIM_THRESHOLD off; 3 = 2 + madvise(MADV_HUGEPAGE)
- *                                                         on the untouched heap above fresh result rows (first-touch
- *                                                         faults: 46 -> 38 ms, opt-in); 0 touches nothing.
- *                                                         Logged at WARNING level the first time
+ *       host_malloc_tuning .............................. 0 (default): the plugin leaves the HOST's allocator alone.
+ *                                                         A host that wants compute_alignments' 2n operator new[]
+ *                                                         result rows cheap (~50 ms instead of ~700 ms per million
+ *                                                         pairs with 16 threads) starts with MALLOC_TOP_PAD_=268435456
+ *                                                         in its environment -- or sets this key:
+ *                                                         2 = mallopt(M_TOP_PAD, 256 MB) from the plugin (process-wide,
+ *                                                         logged at WARNING level the first time), 1 = that +
+ *                                                         M_TRIM_THRESHOLD off.  Other values are refused.
  *       host_packing .................................... score_alignments: 1 (default) sequences cross PCIe as 4-bit
  *                                                         base classes (identical scores), 0 raw ASCII
  *       pointer_scratch_cap_mb .......................... cap of compute_alignments' device-side pointer

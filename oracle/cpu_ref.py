@@ -39,12 +39,46 @@ def build(force=False):
     """Compile libcpuref.so (and oracle/_ref when the reference tree is present)."""
     if _SANITIZED:
         return
-    src = os.path.join(_HERE, "cpu_ref.c")
-    stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))
+    stale = any(not os.path.exists(lib_path) or os.path.getmtime(lib_path) < os.path.getmtime(os.path.join(_HERE, src))
+                for lib_path, src in ((_LIB_PATH, "cpu_ref.c"), (_SIMD_PATH, "cpu_simd.c")))
     if force or stale or not os.path.isdir(REF_DIR):
         subprocess.run(["make", "-C", _HERE, "--no-print-directory"], check=True,
                        stdout=subprocess.DEVNULL)
+
+
+_SIMD_PATH = os.path.join(_SANITIZED or _HERE, "libcpusimd.so")
+_simd = None
+
+
+def simd_lib():
+    """oracle/libcpusimd.so (cpu_simd.c): AVX2, 16 pairs per vector -- the SIMD CPU baseline of bench.py; None where
+    the CPU has no AVX2."""
+    global _simd
+    if _simd is None:
+        if not os.path.exists(_SIMD_PATH):
+            build(force=True)
+        L = ctypes.CDLL(_SIMD_PATH)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.vsimd_score.restype = ctypes.c_int
+        L.vsimd_score.argtypes = [ctypes.c_int] * 5 + [u8p, u8p, ctypes.POINTER(Scoring), ctypes.POINTER(ctypes.c_int16), ctypes.c_int]
+        L.vsimd_available.restype = ctypes.c_int
+        _simd = L
+    return _simd if _simd.vsimd_available() else None
+
+
+def score_simd(opt, reads, refs, scoring=None, threads=1, affine=False):
+    """The scores of score(...) from the AVX2 inter-sequence sweep (cpu_simd.c); raises where AVX2 is missing."""
+    L = simd_lib()
+    if L is None:
+        raise RuntimeError("cpu_simd.c needs AVX2")
+    reads, refs = _check(reads, refs)
+    sc = scoring or Scoring.make()
+    n, R = reads.shape
+    F = refs.shape[1]
+    out = np.zeros(n, dtype=np.int16)
+    L.vsimd_score(opt, 1 if affine else 0, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc),
+                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
+    return out
 
 
 _lib = None

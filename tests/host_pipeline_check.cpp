@@ -90,9 +90,7 @@ void round_trip(int R, int F, long long n, int threads) {
         packer.scatter(sink + k, n - k, st_rows.data() + (size_t)k * 2 * AL, st_idx.data() + 4 * k, threads);
         expect(memcmp(flat_rows.data(), st_rows.data(), (size_t)n * 2 * AL) == 0, "flat scatter in two chunks");
     }
-    for (int variant = 0; variant < 3; ++variant) {              // strings only / whole rows / with the huge-page hint for the rows' heap
-        packer.set_whole_rows(variant == 1);
-        packer.set_huge_rows(variant == 2);
+    {
         std::vector<FakeAlignment> out((size_t)n);
         packer.scatter(out.data(), n, st_rows.data(), st_idx.data(), threads);
         bool ok = true;

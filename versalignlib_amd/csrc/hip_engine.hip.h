@@ -431,8 +431,6 @@ public:
         if (mode < 0 || mode > 2) throw std::runtime_error("ragged_batching must be 0, 1 or 2");
         ragged_ = mode;
     }
-    // transparent huge pages for the arenas compute_alignments' result rows come from (HostPacker::set_huge_rows)
-    void set_huge_rows(bool on) { packer_.set_huge_rows(on); }
     // 4-bit base classes instead of ASCII on the host-pointer score path (host_pipeline.h / pack_kernels.hip.h): 1 on
     // (default), 0 off.  Identical scores; half the bytes across PCIe.
     void set_host_packing(int mode) {

@@ -216,28 +216,22 @@ public:
             // include/AlignmentKernel.h:20-23) -- 1.4 GB per million pairs of 150 x 500, allocated by the scatter threads.
             // glibc grows a thread arena in steps of M_TOP_PAD (128 KB by default), each one an mprotect() under the
             // process's mm lock: with 16 threads that is what the call costs (650-850 ms per million pairs, the bare
-            // allocation loop without any plugin included -- tools/microbench/host_alloc.cpp).  256 MB steps make it
-            // 45-60 ms.  2 (default): M_TOP_PAD only -- address space is reserved in larger steps, pages are still
-            // committed on first touch and returned on free; 1: also never trim (the host keeps freed rows for the next
-            // call: the recycled case without relying on glibc's dynamic threshold); 0: leave the host's allocator alone.
-            const int tuning = opt_param("host_malloc_tuning", 2);
+            // allocation loop without any plugin included -- tools/microbench/host_alloc.cpp; 45-60 ms with 256 MB steps).
+            // That is the HOST's allocator and the host's decision: by default (0) the plugin touches nothing global --
+            // INTEGRATION.md section 0 tells hosts to start with MALLOC_TOP_PAD_=268435456 in their environment.  Only a
+            // host that sets the key itself gets the mallopt() call from here: 2 = M_TOP_PAD 256 MB (address space is
+            // reserved in larger steps, pages are still committed on first touch and returned on free), 1 = that + never
+            // trim (freed rows stay with the process for the next call).
+            const int tuning = opt_param("host_malloc_tuning", 0);
+            if (tuning < 0 || tuning > 2) throw std::runtime_error("host_malloc_tuning must be 0, 1 or 2");
             if (tuning == 1) mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF);
-            if (tuning == 3) {
-                // 3 = 2 + the untouched top of the heap the result rows come out of is recommended for transparent huge pages
-                // (madvise; 350,000 first-touch faults per million pairs become 700 where the system's setting is `madvise`).
-                // Opt-in: the hint stays on that part of the host's heap after the rows are gone.
-                engine_->set_huge_rows(true);
-                for (auto &e : more_) e->set_huge_rows(true);
-            }
-            if (tuning >= 1 && tuning <= 3) {
+            if (tuning >= 1) {
                 mallopt(M_TOP_PAD, 256 << 20);
-
                 // a process-wide setting of the HOST's allocator: said out loud (WARNING level) the first time
                 static std::atomic<bool> told{false};
                 log_line(told.exchange(true) ? 0 : 1, std::string("host_malloc_tuning = ") + std::to_string(tuning) +
                                 ": mallopt(M_TOP_PAD, 256 MB)" + (tuning == 1 ? " + M_TRIM_THRESHOLD off" : "") +
-                                (tuning == 3 ? " + madvise(MADV_HUGEPAGE) on the untouched heap above fresh result rows" : "") +
-                                " for the result rows of compute_alignments (0 leaves the host's allocator alone)");
+                                " for the result rows of compute_alignments (the host asked for it; 0, the default, leaves the host's allocator alone)");
             }
         } catch (const std::exception &e) {
             what_ = std::string("Cannot instantiate Kernel. ") + e.what();

@@ -13,8 +13,8 @@
 #include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -253,38 +253,19 @@ public:
         });
     }
 
-    // Transparent huge pages for the memory the result rows come from (host_malloc_tuning = 3, opt-in): 1.4 GB of fresh rows
-    // per million pairs of 150 x 500 are 350,000 page faults at 4 KB, 700 at 2 MB -- the bare allocate-and-fill loop of 16
-    // threads takes 11-14 ms instead of 22-39 (tools/microbench/host_alloc.cpp mode 4 against mode 0) where the system's
-    // setting is `madvise` (a no-op under `always` / `never`).  glibc hands rows out of 64 MB-aligned arena heaps (or the
-    // brk heap), growing upwards: when a fresh row is the first one in its 64 MB window, the part of the window ABOVE the
-    // row -- reserved by M_TOP_PAD, not touched yet -- gets the hint.  Memory the host already uses (and may have
-    // registered with the GPU) lies below and keeps its pages; what the host allocates there later is huge-page backed.
-    void set_huge_rows(bool on) { huge_rows_ = on; }
-    void set_whole_rows(bool on) { whole_rows_ = on; }       // tuning switch (VALIGN_HIP_COPY_WHOLE_ROWS): copy the rows' zeros too
-
     // staging -> the ABI's Alignment array: two fresh operator new[] rows per pair (the caller delete[]s them)
     template <typename AlignmentT>
     void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
         const size_t AL = (size_t)R_ + F_;
-        const bool huge = huge_rows_;
-        const bool whole_rows = whole_rows_;
         for_ranges(threads, cnt, serial_below_for_rows(AL), [=](int, long long lo, long long hi) {
-            uintptr_t window = 0;
             for (long long i = lo; i < hi; ++i) {
                 AlignmentT &a = alignments[i];
                 a.read = new char[AL ? AL : 1];
                 a.ref = new char[AL ? AL : 1];
-                if (huge && ((uintptr_t)a.ref >> 26) != window) {
-                    window = (uintptr_t)a.ref >> 26;
-                    const uintptr_t from = ((uintptr_t)a.ref + AL + (2u << 20)) & ~(uintptr_t)((2u << 20) - 1);      // next 2 MB boundary above the row
-                    const uintptr_t to = (window + 1) << 26;
-                    if (from < to) (void)madvise((void *)from, (size_t)(to - from), MADV_HUGEPAGE);
-                }
                 // Both rows are right-justified strings that begin at offset idx[0] (= readStart = refStart,
                 // DefaultKernel.cpp:430-456) with zeros in front: only the strings are read out of the staging -- a
                 // third of its bytes at 150 x 500 -- the zeros are written here.
-                size_t start = (idx[4 * i + 0] > 0 && !whole_rows) ? (size_t)idx[4 * i + 0] : 0;
+                size_t start = idx[4 * i + 0] > 0 ? (size_t)idx[4 * i + 0] : 0;
                 if (start > AL) start = AL;
                 const uint8_t *src = rows + (size_t)i * 2 * AL;
                 memset(a.read, 0, start);
@@ -301,8 +282,6 @@ public:
 
 private:
     int R_, F_;
-    bool huge_rows_ = false;
-    bool whole_rows_ = getenv("VALIGN_HIP_COPY_WHOLE_ROWS") != nullptr;
     std::unique_ptr<WorkerPool> pool_;
 };
 
