@@ -820,6 +820,7 @@ def main(argv=None):
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": measured_traffic(pmc_key, n),
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
+                         **({"band_waves_per_cu": d.get("band_waves_per_cu"), "band_lds_per_wave": d.get("band_lds_per_wave")} if long_mode else {}),
                          "kernel_gcups": round(n * RR * FF / (k_ms * 1e-3) / 1e9, 1),
                          "note": "integer VALU bound: %.5f B/cell algorithmic, HBM is idle by design; traffic / valu are quoted "
                                  "from a committed PMC profile only when it was taken from these exact kernel sources (csrc %s)"

@@ -19,9 +19,13 @@
 //     resets that lane's cells, loads its window, rewrites ITS rows of the query profile in place (all 64 lanes
 //     cooperate; the read bases were requested one event earlier), and tops up the group's reference ring
 //     (requested one event earlier as well).  No barrier anywhere: one wave per block.
-//   * int32 cells (one pair per register: the group's two pairs take turns, as in score_long_kernel) read an int32
-//     query profile -- no sign extension per cell (5.5 -> 4.5 VALU per cell) -- laid out [4 rows][slab][lane] so that
-//     a lane's K scores are K/4 ds_read_b128 at 16-byte lane stride (conflict-free within a slab).
+//   * int32 cells (one pair per register: the group's two pairs take turns, as in score_long_kernel).  Round 3 read an
+//     int32 query profile (no sign extension per cell); round 4 packs it as int16, two rows per dword, laid out
+//     [8 rows][slab][lane] so that a lane's K scores are K/8 ds_read_b128 at 16-byte lane stride (conflict-free within a
+//     slab) -- the add that forms the diagonal candidate takes its score straight out of the register half
+//     (v_add_u32_sdwa ... sext WORD_0 / WORD_1: same instruction count).  What it buys is LDS: 18.7 -> 9.5 KB per wave,
+//     sixteen one-wave blocks per CU instead of eight -- the kernel is bound by how often a WAVE may issue, not by
+//     dependency latency (profiles/r04_band_two_chains.txt), so only more waves fill the SIMD's issue slots.
 //
 // tools/band_schedule_model.py states this schedule in plain Python and checks it against the oracle's block band;
 // the constants of the band definition are reported by valign_hip_describe ("band_block_rows", "band_col_align").
@@ -61,14 +65,15 @@ struct BandArgs {
 
 template <int K>
 struct BandLds {
-    static constexpr int kRowChunks = K / 4;
-    static constexpr int kChunkBytes = kBandSlabs * kBandG * 16;          // one 4-row chunk of every slab
+    static constexpr int kRowChunks = K / 8;
+    static constexpr int kChunkBytes = kBandSlabs * kBandG * 16;          // one 8-row chunk (int16 scores) of every slab
     static constexpr int kProf = 0;
     static constexpr int kProfBytes = kRowChunks * kChunkBytes;
-    __host__ __device__ static constexpr int codes() { return kProfBytes; }
+    // (the reference rings are addressed as base | column: aligned to their own size, code_cols a power of two)
+    __host__ __device__ static int codes(int code_cols) { return (kProfBytes + code_cols - 1) / code_cols * code_cols; }
     // (the delay rings are addressed as base | offset: aligned to one lane's ring)
     __host__ __device__ static int ring(int code_cols, int ring_depth) {
-        const int at = kProfBytes + kBandGroups * code_cols, a = ring_depth * 4;
+        const int at = codes(code_cols) + kBandGroups * code_cols, a = ring_depth * 4;
         return (at + a - 1) / a * a;
     }
     // (ring_depth 0: the unit-delay kernel, no ring)
@@ -83,7 +88,7 @@ struct BandLds {
 template <int K, bool SYM, bool UNIT>
 __global__ void __launch_bounds__(64)
 score_band_kernel(const BandArgs args) {
-    static_assert(K % 4 == 0, "rows per lane come in chunks of four");
+    static_assert(K % 8 == 0, "rows per lane come in chunks of eight int16 scores");
     using lay = BandLds<K>;
     const int lane = threadIdx.x;
     const int grp = lane / kBandG;
@@ -91,7 +96,7 @@ score_band_kernel(const BandArgs args) {
     const int R = args.R, F = args.F, d = args.d;
     constexpr int kPairsPerWave = 2 * kBandGroups;
 
-    unsigned char *codes = valign_smem + lay::codes();
+    unsigned char *codes = valign_smem + lay::codes(args.code_cols);
     const unsigned prof_lds = lds_offset(valign_smem);
     const unsigned ring_lds = lds_offset(valign_smem + lay::ring(args.code_cols, UNIT ? 1 : args.ring_depth));
     // delay ring, slot-major: slot s of lane x at ring + s * 256 + x * 4 (a step's 64 stores hit 64 banks)
@@ -100,7 +105,7 @@ score_band_kernel(const BandArgs args) {
     const unsigned my_ring = ring_lds + (unsigned)lane * 4u;
     const unsigned pred_ring = ring_lds + (unsigned)(grp * kBandG + ((l + kBandG - 1) % kBandG)) * 4u;
     const unsigned codes_lds = lds_offset(codes) + (unsigned)grp * (unsigned)args.code_cols;      // aligned to code_cols (<= 2048)
-    // a lane's scores of class slab s: K/4 chunks of 16 bytes at prof + chunk * kChunkBytes + (s * G + l) * 16
+    // a lane's scores of class slab s: K/8 chunks of 16 bytes (8 int16) at prof + chunk * kChunkBytes + (s * G + l) * 16
     const unsigned lane_prof = prof_lds + (unsigned)l * 16u;
     constexpr unsigned kSlabStride = kBandG * 16;
     constexpr unsigned zero_slab = 4 * kBandGroups;                   // (class * kBandGroups + grp for a real class)
@@ -111,6 +116,7 @@ score_band_kernel(const BandArgs args) {
         const int chunk = i / (kBandG * 4), rest = i % (kBandG * 4);
         reinterpret_cast<unsigned *>(valign_smem + chunk * lay::kChunkBytes + zero_slab * kSlabStride)[rest] = 0u;
     }
+    // (the other slabs: every (lane, row) entry is written by the event that starts the lane's block, before its first use)
 
   // A launch is as many one-wave blocks as the device runs side by side (the engine asks the occupancy calculator); every
   // wave takes quads of pairs in turn.  With a block per quad the 32 waves a CU gets for 32,768 pairs went through it in
@@ -132,7 +138,10 @@ score_band_kernel(const BandArgs args) {
 #pragma unroll
     for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
     int up0 = 0, up_in = 0, best = 0;      // up_in: the predecessor's cell for the coming step (read one step ahead)
-    int j = -0x20000000, lo = 0x3FFFFFFF, span = 0;
+    // u: the lane's column minus the first column of its window (inside the window while 0 <= u <= span);
+    // ca: LDS address of the ring entry two columns ahead of the lane's
+    int u = -0x20000000, span = 0;
+    unsigned ca = codes_lds;
     unsigned rd4 = 0;                      // 256 * (t + 1 - delay): the predecessor's slot of the column this lane reaches NEXT step
     unsigned t4 = 0;                       // 256 * t
 
@@ -184,35 +193,46 @@ score_band_kernel(const BandArgs args) {
     unsigned pre_ref0 = 0, pre_ref1 = 0;
     int pre_first = filled, pre_limit = filled;
 
-    int S0[K], S1[K];
+    // this step's and the next step's scores: K int16, rows 2i / 2i + 1 in the halves of dword i
+    unsigned S0[K / 2], S1[K / 2];
 #pragma unroll
-    for (int q = 0; q < K; ++q) S0[q] = S1[q] = 0;
-    unsigned code_next = zero_slab;
-    auto load_scores = [&](unsigned slab, int (&S)[K]) __attribute__((always_inline)) {
-        const unsigned addr = lane_prof + slab * kSlabStride;
+    for (int q = 0; q < K / 2; ++q) S0[q] = S1[q] = 0;
+    // LDS address of the lane's scores for the NEXT step (the slab of its next column; carried as an address: a carried
+    // byte makes the compiler re-mask it every step)
+    unsigned addr_next = lane_prof + zero_slab * kSlabStride;
+    auto load_scores = [&](unsigned addr, unsigned (&S)[K / 2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < K / 4; ++c) {
+        for (int c = 0; c < K / 8; ++c) {
             const u32x4 v = *(lds_cu32x4 *)(addr + c * lay::kChunkBytes);
-            S[4 * c] = (int)v.x; S[4 * c + 1] = (int)v.y; S[4 * c + 2] = (int)v.z; S[4 * c + 3] = (int)v.w;
+            S[4 * c] = v.x; S[4 * c + 1] = v.y; S[4 * c + 2] = v.z; S[4 * c + 3] = v.w;
         }
+    };
+    // row q's score out of its register half, sign-extended (folds into the add that uses it)
+    auto score_of = [](const unsigned (&S)[K / 2], int q) __attribute__((always_inline)) -> int {
+        return (q & 1) ? ((int)S[q >> 1] >> 16) : (int)(short)(S[q >> 1] & 0xFFFFu);
     };
 
     // one step: every lane moves one column on.  `S` holds this step's scores, the loads of the next step's go to Snext.
-    auto step = [&](int (&S)[K], int (&Snext)[K]) __attribute__((always_inline)) {
+    auto step = [&](unsigned (&S)[K / 2], unsigned (&Snext)[K / 2]) __attribute__((always_inline)) {
         const int diag0 = up0;
         up0 = up_in;                                                     // the cell above this block's first row
         if (!UNIT) up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));      // ... of the next step (written >= 1 step ago)
-        load_scores(code_next, Snext);                                   // step t + 1
-        code_next = *(lds_cu8 *)(codes_lds | ((unsigned)(j + 2) & code_mask));   // step t + 2
+        load_scores(addr_next, Snext);                                   // step t + 1
+        // (inline assembly: through the compiler the byte comes back as an "any-extended" load and is masked again every
+        // step; ds_read_u8 zero-extends.  The compiler does not count this load -- LDS returns in order, its own waits only
+        // become more conservative -- so the wait sits with the one use, at the end of the step.)
+        unsigned code;
+        asm volatile("ds_read_u8 %0, %1" : "=v"(code) : "v"(ca));        // step t + 2
+        ca = ((ca + 1u) & code_mask) | codes_lds;
         int h_out = 0;
-        if ((unsigned)(j - lo) <= (unsigned)span) {
+        if ((unsigned)u <= (unsigned)span) {
             int h = up0;
             int up_c = (int)__builtin_elementwise_sub_sat((unsigned)up0, gmag_ref);
-            int d_cur = diag0 + S[0], d_prev = 0;
+            int d_cur = diag0 + score_of(S, 0), d_prev = 0;
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 int d_next = 0;
-                if (q + 1 < K) d_next = Hl[q] + S[q + 1];                // before Hl[q] is overwritten
+                if (q + 1 < K) d_next = Hl[q] + score_of(S, q + 1);      // before Hl[q] is overwritten
                 int left_c = Gl[q];
                 if (!SYM) left_c = (int)__builtin_elementwise_sub_sat((unsigned)Hl[q], gmag_read);
                 int m = d_cur > left_c ? d_cur : left_c;
@@ -233,17 +253,20 @@ score_band_kernel(const BandArgs args) {
             h_out = h;
         }
         if (UNIT) {
-            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window)
-            const unsigned s31 = (unsigned)__builtin_amdgcn_readlane(h_out, 31), s63 = (unsigned)__builtin_amdgcn_readlane(h_out, 63);
-            int v = __builtin_amdgcn_update_dpp(0, h_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-            v = lane == 0 ? (int)s31 : v;
-            up_in = lane == 32 ? (int)s63 : v;
+            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window); the two groups' rings
+            // close through two scalar registers: lane 0 <- lane 31, lane 32 <- lane 63
+            const int s31 = __builtin_amdgcn_readlane(h_out, 31), s63 = __builtin_amdgcn_readlane(h_out, 63);
+            int v = __builtin_amdgcn_update_dpp(h_out, h_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+            asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32" : "+v"(v) : "s"(s31), "s"(s63));
+            up_in = v;
         } else {
             *(__attribute__((address_space(3))) unsigned *)(my_ring + (t4 & ring_mask)) = (unsigned)h_out;
             rd4 += 256;
             t4 += 256;
         }
-        ++j;
+        static_assert(kSlabStride == 512, "the shift below");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %0, %1, 9, %2" : "=v"(addr_next) : "v"(code), "v"(lane_prof));
+        ++u;
     };
 
     // ================= event: block b starts on lane b % G of both groups =================
@@ -259,10 +282,10 @@ score_band_kernel(const BandArgs args) {
 #pragma unroll
             for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
             up0 = 0;
-            j = blk.start;
-            lo = blk.lo;
+            u = blk.start - blk.lo;             // (an empty block: lo = 0x3FFFFFFF -- never inside)
             span = blk.span;
-            code_next = *(lds_cu8 *)(codes_lds | ((unsigned)(blk.start + 1) & code_mask));
+            addr_next = lane_prof + (unsigned)*(lds_cu8 *)(codes_lds | ((unsigned)(blk.start + 1) & code_mask)) * kSlabStride;
+            ca = codes_lds | ((unsigned)(blk.start + 2) & code_mask);
             if (!UNIT) {
                 // this step's cell from above now, the read for the next step follows in the step itself
                 up_in = (int)*(lds_cu32 *)(pred_ring + ((t4 - 256u * (unsigned)blk.delay) & ring_mask));
@@ -271,10 +294,10 @@ score_band_kernel(const BandArgs args) {
         }
         // this lane's entries of lane ls's profile rows (bases requested at the previous event)
         {
-            const unsigned at = ((unsigned)my_q >> 2) * lay::kChunkBytes + (unsigned)ls * 16u + ((unsigned)my_q & 3u) * 4u +
+            const unsigned at = ((unsigned)my_q >> 3) * lay::kChunkBytes + (unsigned)ls * 16u + ((unsigned)my_q & 7u) * 2u +
                                 (unsigned)my_c * (kBandGroups * kSlabStride);
-            *reinterpret_cast<int *>(valign_smem + at) = entry_score(pre_row0);
-            *reinterpret_cast<int *>(valign_smem + at + kSlabStride) = entry_score(pre_row1);
+            *reinterpret_cast<short *>(valign_smem + at) = (short)entry_score(pre_row0);
+            *reinterpret_cast<short *>(valign_smem + at + kSlabStride) = (short)entry_score(pre_row1);
         }
         // requests for the next event (their latency hides behind the d steps in between)
         ++b;

@@ -693,10 +693,13 @@ public:
         const bool sym = sc_.gap_read == sc_.gap_ref && !no_sym_;
         const void *fn = p.unit_delay ? (sym ? (const void *)&score_band_kernel<kBandK, true, true> : (const void *)&score_band_kernel<kBandK, false, true>)
                                       : (sym ? (const void *)&score_band_kernel<kBandK, true, false> : (const void *)&score_band_kernel<kBandK, false, false>);
-        const int lds = BandLds<kBandK>::total(p.code_cols, p.ring_depth);
+        int lds = BandLds<kBandK>::total(p.code_cols, p.ring_depth);
+        if (const char *pad = getenv("VALIGN_HIP_BAND_LDS_PAD")) lds += atoi(pad);       // experiment: fewer waves per CU
         // as many one-wave blocks as run side by side; each takes quads of pairs in turn (band_kernels.hip.h)
         int per_cu = 0;
         hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, (size_t)lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+        band_blocks_per_cu_ = per_cu;
+        band_lds_ = lds;
         const long long resident = (long long)std::max(per_cu, 1) * std::max(cu_count_, 1);
         const long long blocks = no_band_persist_ ? (n + 3) / 4 : std::min<long long>((n + 3) / 4, resident);
         if (blocks > 0x7FFFFFFFll) throw std::runtime_error("batch too large for one launch");
@@ -1591,13 +1594,13 @@ public:
 
     std::string describe(int opt, long long n) const {
         const long long ppb = (long long)plan_.pairs_per_wave * plan_.waves_per_block;
-        char buf[1400];
+        char buf[1600];
         snprintf(buf, sizeof buf,
                  "{\"arch\": \"%s\", \"device\": %d, \"alg\": %d, \"affine\": %d, \"group_lanes\": %d, "
                  "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
                  "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
                  "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"band_block_rows\": %d, \"band_col_align\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+                 "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"band_block_rows\": %d, \"band_col_align\": %d, \"band_waves_per_cu\": %d, \"band_lds_per_wave\": %d, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
                  arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
                  plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
                  plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
@@ -1605,7 +1608,7 @@ public:
                  host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
                  score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.packed, host_stats_.direct_out,
                  ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? kBandK : VALIGN_HIP_BAND_BLOCK_ROWS,
-                 ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? 1 : VALIGN_HIP_BAND_COL_ALIGN, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+                 ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? 1 : VALIGN_HIP_BAND_COL_ALIGN, band_blocks_per_cu_, band_lds_, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
                  host_stats_.drain_ms);
         return buf;
     }
@@ -2237,6 +2240,7 @@ private:
     // compute_alignments: pointer scratch + end cells (device), result staging (both sides)
     BandPlan band_plan_;               // banded linear SW: the block chain's plan for band_plan_width_, its tables on the device
     int band_plan_width_ = -1;
+    int band_blocks_per_cu_ = 0, band_lds_ = 0;          // of the last block-chain launch (describe)
     BandBlock *d_band_blocks_ = nullptr;
     int *d_band_fill_ = nullptr;
     int cu_count_ = 0;
