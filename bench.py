@@ -282,10 +282,37 @@ def host_cores():
 BAND_BLOCK = [160, 4]       # (block rows, column alignment) of the band the engine computes: set from its describe()
 
 
-def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
-    """Oracle on the host cores over a bounded sample of the same batch (rank 0, N == 1): threads = the CPUs this
-    process really has (host_cpus).  Returns (record, oracle scores of the sample) -- the scores are what the timed
-    kernel's output is verified against."""
+def cpu_simd_baseline(reads, refs, affine, cores, seconds):
+    """The AVX2 inter-sequence sweep of oracle/cpu_simd.c (16 pairs per vector, OpenMP over batches: what the reference's
+    AVX2 kernel does for the linear model on ONE thread, here for both gap models on all the CPUs this process has),
+    on a bounded sample of the same batch -- checked against the scalar oracle on its first pairs."""
+    import numpy as np
+    from oracle import cpu_ref
+    if cpu_ref.simd_lib() is None:
+        return {"error": "no AVX2 on this host"}
+    sc = cpu_ref.Scoring.make(2, -1, -3, -3, **(AFFINE if affine else {}))
+    probe = min(int(reads.shape[0]), 4096 * cores)
+    h_reads, h_refs = reads[:probe].cpu().numpy(), refs[:probe].cpu().numpy()
+    t0 = time.perf_counter()
+    got = cpu_ref.score_simd(0, h_reads, h_refs, sc, threads=cores, affine=affine)
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    check = min(probe, 2048)
+    same = bool(np.array_equal(got[:check], cpu_ref.score(0, h_reads[:check], h_refs[:check], sc, threads=cores, affine=affine)))
+    sample = int(min(reads.shape[0], max(probe, rate * seconds)))
+    h_reads, h_refs = reads[:sample].cpu().numpy(), refs[:sample].cpu().numpy()
+    t0 = time.perf_counter()
+    cpu_ref.score_simd(0, h_reads, h_refs, sc, threads=cores, affine=affine)
+    sec = time.perf_counter() - t0
+    return {"value": round(float(sample) * R * F / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "identical_to_scalar_oracle": same,
+            "sample": "first %d pairs of the rank-0 batch, SW %s int16, oracle/cpu_simd.c (AVX2, 16 pairs per vector, OpenMP over "
+                      "batches) on %d threads, %.1f s" % (sample, "affine-gap" if affine else "linear-gap", cores, sec)}
+
+
+def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0, simd_seconds=6.0):
+    """Oracle on the host cores over a bounded sample of the same batch (rank 0; N > 1: a short sample while the other
+    ranks wait): threads = the CPUs this process really has (host_cpus).  Returns (record, oracle scores of the
+    sample) -- the scores are what the timed kernel's output is verified against.  `simd`: the AVX2 sweep beside it."""
     from oracle import cpu_ref
     cpu_ref.build()
     cpus = host_cpus()
@@ -310,7 +337,13 @@ def cpu_baseline(reads, refs, affine, R=R, F=F, band=0, seconds=12.0):
     sec = time.perf_counter() - t0
     what = "SW %s int16" % ("affine-gap" if affine else "linear-gap") if not band else "SW linear-gap banded (%d diagonals)" % band
     cells = float(sample) * R * F
-    return {"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "logical_cpus": cpus["logical_cpus"],
+    simd = None
+    if not band and simd_seconds > 0:
+        try:
+            simd = cpu_simd_baseline(reads, refs, affine, cores, simd_seconds)
+        except Exception as e:      # the SIMD leg must never take the line with it
+            simd = {"error": str(e)[:200]}
+    return {"simd": simd, "value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": cores, "logical_cpus": cpus["logical_cpus"],
             "affinity_cpus": cpus["affinity"], "cpu_quota": cpus["cpu_quota"], "kind": "port",
             "sample": "first %d pairs of the rank-0 batch, %s, oracle/cpu_ref.c OpenMP over pairs on %d threads (= the CPUs "
                       "the cgroup quota and the affinity mask give this process), %.1f s%s"
@@ -484,38 +517,6 @@ def in_plugin_shards_child(devices, threads):
     return out
 
 
-def child_huge_rows(threads, device):
-    """The child: compute_alignments(SW) through the ABI with host_malloc_tuning = 3 (the untouched heap above fresh result
-    rows recommended for transparent huge pages) -- fresh rows (earlier results alive) and recycled rows, as in abi_leg."""
-    from versalignlib_amd import build, host, synth
-    import numpy as np
-    blk = 1 << 16
-    r0, f0 = synth.make_pairs(blk, R, F, seed=2000)
-    h_reads, h_refs = np.tile(r0, (PAIRS_PER_GPU // blk, 1)), np.tile(f0, (PAIRS_PER_GPU // blk, 1))
-    n = int(h_reads.shape[0])
-    keys = dict(score_gap_open_read=AFFINE["open_read"], score_gap_extend_read=AFFINE["ext_read"],
-                score_gap_open_ref=AFFINE["open_ref"], score_gap_extend_ref=AFFINE["ext_ref"])
-    if device:
-        keys["hip_device"] = device
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=3, **keys) as k:
-        k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
-        _, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=False)
-        phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
-        out = {"ms_fresh_rows": round(min(per_call[1:]) * 1e3, 2),
-               "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
-        _, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=True)
-        out["ms_recycled_rows"] = round(min(per_call[1:]) * 1e3, 2)
-    try:
-        with open("/sys/kernel/mm/transparent_hugepage/enabled") as f:
-            out["transparent_hugepage"] = f.read().strip()
-    except OSError:
-        pass
-    out["note"] = ("host_malloc_tuning = 3 (opt-in): madvise(MADV_HUGEPAGE) on the untouched heap above fresh result rows; measured in a "
-                   "child process of the bench")
-    print(json.dumps(out), flush=True)
-    return 0
-
-
 def child_in_plugin_shards(devices, threads):
     """The child: synthetic host sequences (no torch, no rank), the plugin with hip_devices = N: score_alignments with the
     host-side merge of the shards and with the in-plugin RCCL all-gather, checked against each other and against one device."""
@@ -558,16 +559,18 @@ def abi_leg(reads, refs, threads):
     out = {"threads": threads, "pairs": n, "note": "through spawn_alignment_kernel with one heap block per sequence; "
                                                     "PCIe and host gather/scatter included; never part of `value`"}
     # compute_alignments(SW) hands out 2n operator new[] rows per call (include/AlignmentKernel.h:20-23).  What that costs
-    # is glibc's arena growth: 128 KB steps (an mprotect each, 16 threads contending) by default, 256 MB steps with the
-    # plugin's default host_malloc_tuning = 2 (mallopt(M_TOP_PAD), process-wide and sticky: the untuned figures first).
+    # is glibc's arena growth: 128 KB steps (an mprotect each, 16 threads contending) by default -- the plugin's default
+    # since round 4 (host_malloc_tuning = 0: it leaves the host's allocator alone) -- and 256 MB steps where the HOST opts
+    # in: MALLOC_TOP_PAD_=268435456 in its environment, or the key host_malloc_tuning = 2, which is what this bench, as
+    # the host, sets for the legs below (mallopt(M_TOP_PAD): process-wide and sticky, hence the untuned figures first).
     untuned = None
     if True:                    # (the first plugin object of the process: nothing has changed the allocator yet)
-        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=0, **keys) as k:
+        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
             floor_untuned, _ = host.alloc_probe(n, R + F, threads)
             k.time_calls(0, h_reads[:65536], h_refs[:65536], reps=1, align=True, free_between=False)
             _, per_call = k.time_calls(0, h_reads, h_refs, reps=2, align=True, free_between=False)
             untuned = {"ms_fresh_rows": round(min(per_call) * 1e3, 2), "ms_2n_fresh_new_rows_alone": round(floor_untuned * 1e3, 2),
-                       "note": "host_malloc_tuning = 0: glibc's default 128 KB arena steps"}
+                       "note": "the plugin's default (host_malloc_tuning = 0): glibc's own 128 KB arena steps"}
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
         k.score_alignments(0, h_reads[:65536], h_refs[:65536], scattered=True)
         k.score_alignments(0, h_reads, h_refs, scattered=True)
@@ -582,7 +585,7 @@ def abi_leg(reads, refs, threads):
         secs = sorted(k0.score_alignments(0, h_reads, h_refs, scattered=True)[1] for _ in range(4))
         out["score_alignments_sw_ascii"] = {"ms": round(secs[0] * 1e3, 2), "gcups": round(n * R * F / secs[0] / 1e9, 1),
                                             "transport": "raw ASCII (host_packing = 0)"}
-    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, **keys) as k:
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, host_malloc_tuning=2, **keys) as k:
         # compute_alignments(SW): 2n operator new[] rows per call (include/AlignmentKernel.h:20-23).
         # "fresh": rows of earlier calls are still alive, as in the reference's timing loop, which leaks them
         # (main.cpp:280-285) -- every call gets memory the process has never touched.  "recycled": the host
@@ -594,6 +597,7 @@ def abi_leg(reads, refs, threads):
         phases = [ln for ln in k.drain_log().splitlines() if "align done" in ln]
         out["compute_alignments_sw"] = {"ms_fresh_rows": round(fresh * 1e3, 2), "gcups_fresh_rows": round(n * R * F / fresh / 1e9, 1),
                                         "ms_2n_fresh_new_rows_alone": round(floor_fresh * 1e3, 2),
+                                        "host_malloc_tuning": "2, set by this bench as the host (= MALLOC_TOP_PAD_=268435456); the plugin's default is 0",
                                         "host_malloc_tuning_0": untuned,
                                         "host_phases_last_call": json.loads(phases[-1].split("host phases ")[-1]) if phases else None}
         total, per_call = k.time_calls(0, h_reads, h_refs, reps=3, align=True, free_between=True)
@@ -659,6 +663,28 @@ def abi_leg(reads, refs, threads):
 # `python bench.py --gpus N` -> child ranks -> all-gather -> one JSON line can be tested without a GPU
 # ---------------------------------------------------------------------------------------------
 
+def roofline_record(n, RR, FF, k_ms, kernel_name, pmc_key, extra=None):
+    """The `roofline` object of the line: algorithmic bytes of one launch (R + F + 2 per pair) over the
+    dominant kernel's launch time (HIP events on its own stream, kernel_launch_ms) against the 8 TB/s HBM peak; measured
+    traffic / VALU issue / LDS conflicts quoted from the committed PMC profile of exactly these kernel sources.
+    k_ms None (the launcher's CPU self-test, which runs no kernel): the same keys, nothing achieved."""
+    alg_bytes = float(n) * (RR + FF + 2)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms else None
+    rec = {"bound": "hbm", "achieved": round(achieved, 2) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBPS, 6) if achieved is not None else None,
+           "traffic": measured_traffic(pmc_key, n) if k_ms else None,
+           "kernel": kernel_name, "kernel_ms": round(k_ms, 4) if k_ms else None, "algorithmic_bytes": alg_bytes,
+           "kernel_gcups": round(n * RR * FF / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
+           "note": "integer VALU bound: %.5f B/cell algorithmic, HBM is idle by design; traffic / valu are quoted "
+                   "from a committed PMC profile only when it was taken from these exact kernel sources (csrc %s)"
+                   % ((RR + FF + 2) / (RR * FF), source_hash()),
+           "valu": measured_valu_issue(pmc_key, n) if k_ms else None,
+           "lds_bank_conflict_frac": measured_lds_conflicts(pmc_key, n) if k_ms else None}
+    if extra:
+        rec.update(extra)
+    return rec
+
+
 def selftest_rank(args, world, rank):
     import torch
     import torch.distributed as dist
@@ -673,9 +699,15 @@ def selftest_rank(args, world, rank):
     mine = torch.tensor([int(local.to(torch.int64).sum())], dtype=torch.int64)
     dist.all_reduce(mine)
     if rank == 0:
+        # the CPU leg of a real N > 1 line, on a small synthetic batch: rank 0 runs the oracle while the others wait below
+        from versalignlib_amd import synth
+        h_reads, h_refs = synth.make_pairs(512, R, F, seed=2000)
+        cpu, _ = cpu_baseline(torch.from_numpy(h_reads), torch.from_numpy(h_refs), affine=True, seconds=0.2, simd_seconds=0.1)
         print(json.dumps({"metric": "launcher self-test (no alignment computed)", "value": 0.0, "unit": "none",
                           "n_gpus": world, "steps": args.steps, "warmup": 0, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "data": "launcher-selftest", "backend": "gloo",
+                          "roofline": roofline_record(n, R, F, None, "(none: the self-test runs no kernel)", ""),
+                          "cpu_baseline": cpu,
                           "multi_gpu": {"n_ranks_seen": dist.get_world_size(), "gathered_pairs": int(full.numel()),
                                         "gather_checksum": int(full.to(torch.int64).sum()),
                                         "sum_of_rank_checksums": int(mine.item()),
@@ -700,15 +732,12 @@ def main(argv=None):
     ap.add_argument("--no-abi", action="store_true", help="skip the plugin-ABI (PCIe-inclusive) leg")
     ap.add_argument("--abi-threads", type=int, default=0, help="num_threads of the ABI leg (default: host cores, <= 16)")
     ap.add_argument("--child-in-plugin-shards", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--child-huge-rows", type=int, default=-1, help=argparse.SUPPRESS)     # value: the device
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU/gloo self-test of launcher + all-gather + result relay; computes no alignment")
     args = ap.parse_args(argv)
 
     if args.child_in_plugin_shards:
         return child_in_plugin_shards(args.child_in_plugin_shards, args.abi_threads or 16)
-    if args.child_huge_rows >= 0:
-        return child_huge_rows(args.abi_threads or 16, args.child_huge_rows)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -756,9 +785,8 @@ def main(argv=None):
     else:
         # `value` is the int16-cell kernel BASELINE.json names; the half-float-cell kernel the engine would
         # pick by itself for this scoring is reported beside it (half_float)
-        os.environ["VALIGN_HIP_NO_F16"] = "1"
         eng = hipkernel.Engine(RR, FF, affine_sc, device=local_rank)
-        del os.environ["VALIGN_HIP_NO_F16"]
+        eng.set_half_float_cells(0)
     local = torch.empty(n, dtype=torch.int16, device=device)
     gathered = [None]
 
@@ -792,8 +820,6 @@ def main(argv=None):
     if rank == 0:
         assert gathered[0].numel() == n * world
         k_ms = kernel_launch_ms(eng, 0, reads, refs, local, max(3, min(args.steps, 10)))
-        alg_bytes = float(n) * (RR + FF + 2)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         d = eng.describe(0, n)
         cells = d.get("score_cells", "int16")
         if long_mode:
@@ -816,17 +842,8 @@ def main(argv=None):
             "vs_baseline": None, "dtype": cells, "data": "synthetic",
             "config": {"workload": workload, "pairs_per_gpu": n, "read_length": RR, "ref_length": FF,
                        "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": measured_traffic(pmc_key, n),
-                         "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
-                         **({"band_waves_per_cu": d.get("band_waves_per_cu"), "band_lds_per_wave": d.get("band_lds_per_wave")} if long_mode else {}),
-                         "kernel_gcups": round(n * RR * FF / (k_ms * 1e-3) / 1e9, 1),
-                         "note": "integer VALU bound: %.5f B/cell algorithmic, HBM is idle by design; traffic / valu are quoted "
-                                 "from a committed PMC profile only when it was taken from these exact kernel sources (csrc %s)"
-                                 % ((RR + FF + 2) / (RR * FF), source_hash()),
-                         "valu": measured_valu_issue(pmc_key, n),
-                         "lds_bank_conflict_frac": measured_lds_conflicts(pmc_key, n)},
+            "roofline": roofline_record(n, RR, FF, k_ms, kernel_name, pmc_key,
+                                        {"band_waves_per_cu": d.get("band_waves_per_cu"), "band_lds_per_wave": d.get("band_lds_per_wave")} if long_mode else None),
         }
         if multi is not None:
             line["multi_gpu"] = multi
@@ -894,9 +911,6 @@ def main(argv=None):
                     # the plugin picks the half-float-cell kernel for this scoring: that is the kernel the call contains
                     for key in ("score_alignments_sw", "score_alignments_sw_ascii"):
                         line["abi"][key]["ratio_to_kernel_ms"] = round(line["abi"][key]["ms"] / line["half_float"]["kernel_ms"], 3)
-                    # ... and the fresh-row call with the opt-in huge-page hint, in a child process
-                    line["abi"]["compute_alignments_sw"]["host_malloc_tuning_3"] = run_child_leg(
-                        ["--child-huge-rows", local_rank, "--abi-threads", threads], keep_devices=True)
                 except Exception as e:
                     line["abi"] = {"error": str(e)[:300]}
                 visible = torch.cuda.device_count()
@@ -907,13 +921,20 @@ def main(argv=None):
                     # not take the rank that prints the line with it.
                     line["abi_in_plugin_shards"] = in_plugin_shards_child(min(world, visible), args.abi_threads or min(16, host_cores()))
         oracle_scores = None
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:
+            # N == 1: the full CPU legs (10-30 s).  N > 1: the same oracle on a short sample (~1.5 s + ~1 s of the AVX2
+            # sweep) on rank 0's host CPUs while the other ranks wait at the final barrier -- the CPU path timed "in the
+            # same run" at every N, without holding N - 1 GPUs for half a minute
+            short = world > 1
             if long_mode:
-                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=False, R=RR, F=FF, band=LONG_BAND)
+                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=False, R=RR, F=FF, band=LONG_BAND,
+                                                                   seconds=1.5 if short else 12.0)
             else:
-                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=True)
-                line["linear_gap"]["cpu_port"], _ = cpu_baseline(reads, refs, affine=False)
-                line["linear_gap"]["cpu_reference"] = reference_cpu_kernels(reads, refs)
+                line["cpu_baseline"], oracle_scores = cpu_baseline(reads, refs, affine=True, seconds=1.5 if short else 12.0,
+                                                                   simd_seconds=1.0 if short else 6.0)
+                if not short:
+                    line["linear_gap"]["cpu_port"], _ = cpu_baseline(reads, refs, affine=False, simd_seconds=3.0)
+                    line["linear_gap"]["cpu_reference"] = reference_cpu_kernels(reads, refs)
         # the timed kernel's own output against the oracle, in this very run: the sample cpu_baseline scored (or a
         # small fresh one when the CPU legs are off / N > 1); a mismatch fails the run
         line["verified"] = verify_scores(timed_scores, reads, refs, affine=not long_mode, R=RR, F=FF,

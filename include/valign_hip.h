@@ -37,6 +37,8 @@
  *                                                         M_TRIM_THRESHOLD off.  Other values are refused.
  *       host_packing .................................... score_alignments: 1 (default) sequences cross PCIe as 4-bit
  *                                                         base classes (identical scores), 0 raw ASCII
+ *       half_float_cells ................................ score_alignments: 1 (default) half-float cells where they are
+ *                                                         exact (identical scores, fewer instructions), 0 integer cells
  *       pointer_scratch_cap_mb .......................... cap of compute_alignments' device-side pointer
  *                                                         scratch in MiB (default 0: 64 GiB / half the free HBM)
  *       hip_device ...................................... device ordinal (default 0)
@@ -191,6 +193,11 @@ int valign_hip_host_unregister(void *ptr);
  * ever look at the class of a base (DefaultKernel.h:43-60), so scores are identical; 0 = raw ASCII.  Plugin key:
  * host_packing.  Alignments always travel as the caller's bytes (they are copied into the result rows).                 */
 int valign_hip_set_host_packing(valign_hip_engine *e, int mode);
+
+/* score_alignments: 1 (default) = the recurrences run on packed half floats wherever every cell provably stays a small
+ * integer (exact, bit-identical scores; v_pk_maximum3_f16 saves instructions), 0 = integer cells only.  Plugin key:
+ * half_float_cells.                                                                                                      */
+int valign_hip_set_half_float_cells(valign_hip_engine *e, int mode);
 
 /* JSON description of what a call with this opt would launch (geometry, LDS, grid).   */
 int valign_hip_describe(valign_hip_engine *e, int opt, long long n, char *buf, int cap);

@@ -25,6 +25,24 @@ def _built_libraries():
     yield
 
 
+def debug_switches(monkeypatch, **switches):
+    """Set / clear entries of VALIGN_HIP_DEBUG -- the library's ONE environment variable, read when an engine is created
+    ("name[=value],..."; tests and experiments only).  `name=None` removes an entry, `name=1` sets a flag."""
+    current = {}
+    for item in filter(None, os.environ.get("VALIGN_HIP_DEBUG", "").split(",")):
+        name, _, value = item.partition("=")
+        current[name] = value
+    for name, value in switches.items():
+        if value is None:
+            current.pop(name, None)
+        else:
+            current[name] = str(int(value))
+    if current:
+        monkeypatch.setenv("VALIGN_HIP_DEBUG", ",".join("%s=%s" % kv for kv in sorted(current.items())))
+    else:
+        monkeypatch.delenv("VALIGN_HIP_DEBUG", raising=False)
+
+
 def ref_kernel(name):
     """Path of a reference kernel compiled by oracle/Makefile, or None when absent."""
     path = os.path.join(ROOT, "oracle", "_ref", "lib%sKernel.so" % name)

@@ -29,6 +29,21 @@ def test_plain_command_starts_two_ranks_and_relays_one_line():
     m = line["multi_gpu"]
     assert m["n_ranks_seen"] == 2 and m["gathered_pairs"] == 2002
     assert m["checksum_ok"] and m["gather_checksum"] == m["sum_of_rank_checksums"]
+    # an N > 1 line carries the CPU baseline (rank 0 times the oracle on a short sample while the other ranks wait)
+    # and the roofline object, with the same keys as the N = 1 line
+    cpu = line["cpu_baseline"]
+    assert cpu["value"] > 0 and cpu["unit"] == "GCUPS" and cpu["cores"] >= 1 and cpu["kind"] == "port" and "sample" in cpu
+    assert cpu["simd"] is None or "error" in cpu["simd"] or (cpu["simd"]["value"] > 0 and cpu["simd"]["identical_to_scalar_oracle"])
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and roof["peak"] == 8000.0
+
+
+def test_real_line_builds_its_cpu_leg_for_every_world_size():
+    """bench.py's N > 1 path must not skip `cpu_baseline` (round 3 did): the condition in main() is `not args.no_cpu`,
+    with the short sample for world > 1."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "if world == 1 and not args.no_cpu" not in src
+    assert "short = world > 1" in src and "seconds=1.5 if short else 12.0" in src
 
 
 def test_failing_ranks_fail_the_command():

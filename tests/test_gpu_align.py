@@ -7,7 +7,7 @@ import pytest
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
 
-from conftest import ref_kernel
+from conftest import ref_kernel, debug_switches
 from golden_util import golden_files, load
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +75,7 @@ def test_plugin_alignments_match_reference_default_live():
             _assert_same(hip.compute_alignments(opt, reads, refs), d.compute_alignments(opt, reads, refs), opt)
 
 
-@pytest.mark.parametrize("geom", [(8, 20), (16, 10), (32, 8), (64, 12)])
+@pytest.mark.parametrize("geom", [(16, 10), (16, 12), (32, 8), (32, 10), (64, 12)])
 def test_alignment_geometries(geom):
     R, F, n = 150, 500, 131
     reads, refs = _data(R, F, n, 23)
@@ -287,9 +287,9 @@ def test_host_malloc_tuning_key_changes_nothing_but_the_allocator(tuning):
 @pytest.mark.parametrize("kind", ["linear", "linear_asym", "sse", "affine", "affine_asym"])
 def test_equality_test_kernels_stay_correct(monkeypatch, kind):
     """The tagged-cell kernels are the default; beyond their int16 headroom the engine falls back to the
-    kernels that derive pointers by equality tests.  VALIGN_HIP_NO_TAG forces that path: same alignments."""
+    kernels that derive pointers by equality tests.  VALIGN_HIP_DEBUG no_tag forces that path: same alignments."""
     import torch
-    monkeypatch.setenv("VALIGN_HIP_NO_TAG", "1")
+    debug_switches(monkeypatch, no_tag=1)
     R, F, n = 150, 500, 700
     reads, refs = _data(R, F, n, 97)
     kw, policy, gaps = {}, "default", (-3, -3)
@@ -390,14 +390,14 @@ def test_pointer_scratch_follows_the_widest_stream_of_an_engine(aff, order):
 def test_fused_small_batch_kernel(monkeypatch, R, F, n, seed, gaps):
     """Small compute_alignments calls run fill + traceback in ONE launch with the pointer stream in LDS
     (align_fill_tag_kernel<..., FUSED>): same alignments as the oracle and as the three-kernel path
-    (VALIGN_HIP_NO_FUSED), odd pair counts and half-empty waves included."""
+    (VALIGN_HIP_DEBUG no_fused), odd pair counts and half-empty waves included."""
     reads, refs = _data(R, F, n, seed)
     sc = hipkernel.Scoring.make(2, -1, gaps[0], gaps[1])
     osc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
     eng = hipkernel.Engine(R, F, sc)
-    monkeypatch.setenv("VALIGN_HIP_NO_FUSED", "1")
+    debug_switches(monkeypatch, no_fused=1)
     plain = hipkernel.Engine(R, F, sc)
-    monkeypatch.delenv("VALIGN_HIP_NO_FUSED")
+    debug_switches(monkeypatch, no_fused=None)
     for opt in (host.SW, host.NW):
         exp = cpu_ref.align(opt, reads, refs, osc, threads=8)
         got = eng.align_host(opt, reads, refs, threads=2)
@@ -414,13 +414,13 @@ def test_fused_small_batch_kernel(monkeypatch, R, F, n, seed, gaps):
 def test_tracebacks_beside_the_next_fill(monkeypatch, cap_mb, overlap):
     """Large device batches run the walk of one part on a helper stream beside the fill of the next: one 7/8 + 1/8 cut
     when the pointer scratch holds the batch, the two halves of the scratch in turn when it does not (forced here by
-    VALIGN_HIP_SCRATCH_CAP_MB).  Rows and coordinates must repeat with the period of the repeated block and equal the
+    VALIGN_HIP_DEBUG scratch_cap_mb).  Rows and coordinates must repeat with the period of the repeated block and equal the
     oracle on it, with and without the helper stream."""
     import torch
     if cap_mb:
-        monkeypatch.setenv("VALIGN_HIP_SCRATCH_CAP_MB", str(cap_mb))
+        debug_switches(monkeypatch, scratch_cap_mb=cap_mb)
     if not overlap:
-        monkeypatch.setenv("VALIGN_HIP_NO_OVERLAP", "1")
+        debug_switches(monkeypatch, no_overlap=1)
     R, F, blk, reps = 150, 500, 2039, 70          # 142 730 pairs (not a multiple of a block) = 1.07e10 cells: above the overlap threshold
     reads, refs = synth.make_pairs(blk, R, F, seed=77, indel_rate=0.01, junk_frac=0.02)
     eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3))
@@ -443,7 +443,7 @@ def test_tracebacks_beside_the_next_fill(monkeypatch, cap_mb, overlap):
 def test_sw_end_cell_key_in_the_profile_or_computed(monkeypatch, R, F, match, prof_key):
     """Smith-Waterman alignments pick the row-major first maximum from one key per lane (value, then earlier row).
     Where 64x the cell range fits int16 (min(R, F) * match <= 497) the key rides in the query profile; beyond, and with
-    VALIGN_HIP_NO_PROF_KEY, it is computed per register.  Same rows and coordinates as the oracle from both, on a batch
+    VALIGN_HIP_DEBUG no_prof_key, it is computed per register.  Same rows and coordinates as the oracle from both, on a batch
     with many equal maxima (perfect repeats make the first-maximum rule matter)."""
     import torch
     n = 777
@@ -454,7 +454,7 @@ def test_sw_end_cell_key_in_the_profile_or_computed(monkeypatch, R, F, match, pr
     d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
     for computed in (False, True):
         if computed:
-            monkeypatch.setenv("VALIGN_HIP_NO_PROF_KEY", "1")
+            debug_switches(monkeypatch, no_prof_key=1)
         eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(match, -1, -3, -3))
         rows, idx = eng.align_device(0, d_reads, d_refs)
         torch.cuda.synchronize()

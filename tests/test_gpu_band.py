@@ -3,7 +3,7 @@
 Every lane sweeps only the band window of its own 16-row block and hands its bottom row on through an LDS delay
 ring; the result must equal the oracle's block band with the constants the library reports for the engine
 (valign_hip_describe: band_block_rows = 16, band_col_align = 1), sit between the per-cell band and the full matrix,
-and equal score_long_kernel's strips (VALIGN_HIP_NO_BAND_CHAIN) on THEIR block definition.  Shapes are chosen for the
+and equal score_long_kernel's strips (VALIGN_HIP_DEBUG no_band_chain) on THEIR block definition.  Shapes are chosen for the
 schedule's corners: slopes F / R above and below one (window starts that advance by varying amounts), a single strip
 that is mostly top padding, reads that end inside a block, windows clipped at both matrix edges, bands from 2
 diagonals to almost the matrix, pair counts that leave the last wave short."""
@@ -12,6 +12,7 @@ import pytest
 
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
+from conftest import debug_switches
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +61,7 @@ def test_block_chain_against_the_strip_kernel(monkeypatch):
     eng.set_band_width(band)
     chain = eng.score_host(0, reads, refs, threads=4)
     eng.close()
-    monkeypatch.setenv("VALIGN_HIP_NO_BAND_CHAIN", "1")
+    debug_switches(monkeypatch, no_band_chain=1)
     eng = hipkernel.Engine(R, F)
     eng.set_band_width(band)
     d = eng.describe(0, n)

@@ -9,6 +9,7 @@ import pytest
 
 from oracle import cpu_ref
 from versalignlib_amd import hipkernel, host, synth
+from conftest import debug_switches
 
 pytestmark = pytest.mark.gpu
 
@@ -61,8 +62,8 @@ def test_random_configuration(case, monkeypatch):
     if case % 3 == 0:
         # every third configuration through the chunk pipeline whatever its size: 4-bit classes across PCIe, several
         # staging slots (round 3); the others take the direct path small calls take by themselves
-        monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")
-        monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(1 << 14))
+        debug_switches(monkeypatch, direct_bytes=0)
+        debug_switches(monkeypatch, chunk_bytes=1 << 14)
     R, F, n = c["R"], c["F"], c["n"]
     reads, refs = synth.make_pairs(n, R, F, seed=c["seed"], indel_rate=0.03, n_run_frac=0.05, short_frac=0.1,
                                    lowercase_frac=0.03, junk_frac=0.03)
@@ -94,7 +95,7 @@ def test_random_configuration(case, monkeypatch):
     if case % 4 == 1:
         # length-sorted batching on the device (ragged_kernels.hip.h): mixed-length pairs, every configuration's scoring,
         # device-resident and through the host pipeline -- identical to the padded sweep
-        monkeypatch.setenv("VALIGN_HIP_RAGGED_MIN", "8")
+        debug_switches(monkeypatch, ragged_min=8)
         rr, rf = synth.make_ragged_pairs(n, R, F, seed=c["seed"] + 7, n_run_frac=0.05, short_frac=0.05, junk_frac=0.03)
         eng = hipkernel.Engine(R, F, hsc)
         eng.set_ragged_batching(2)

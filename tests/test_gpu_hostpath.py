@@ -6,6 +6,7 @@ import pytest
 
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
+from conftest import debug_switches
 
 pytestmark = pytest.mark.gpu
 
@@ -20,8 +21,8 @@ def _data(R, F, n, seed):
 def test_packed_classes_give_identical_scores(monkeypatch, R, F, n, seed):
     """Every byte value, lower case, N runs, NUL padding, odd lengths: classes in, the scores of the bytes out.
     Small chunks so that several staging slots and a short last chunk are in play."""
-    monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")              # the chunk pipeline, whatever the size
-    monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(1 << 18))
+    debug_switches(monkeypatch, direct_bytes=0)              # the chunk pipeline, whatever the size
+    debug_switches(monkeypatch, chunk_bytes=1 << 18)
     reads, refs = _data(R, F, n, seed)
     for gaps in ((-3, -3), (-2, -4)):
         sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
@@ -41,7 +42,7 @@ def test_packed_classes_give_identical_scores(monkeypatch, R, F, n, seed):
 
 def test_packed_classes_affine_long_and_flat_entry(monkeypatch):
     """The same transport in front of the affine kernels, the strip (long-read) kernels and the flat entry point."""
-    monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")
+    debug_switches(monkeypatch, direct_bytes=0)
     R, F, n = 150, 500, 5003
     reads, refs = _data(R, F, n, 11)
     aff = (-5, -1, -4, -2)
@@ -72,7 +73,7 @@ def test_flat_results_go_straight_into_registered_buffers(monkeypatch):
     """valign_hip_align_host into buffers the caller registered once (valign_hip_host_register): the device's copy
     engine writes them directly (`direct_out`), chunk after chunk; unregistered buffers take the staged path; both
     equal the oracle.  Default tie-breaks and the SSE policy, linear and affine."""
-    monkeypatch.setenv("VALIGN_HIP_ALIGN_CHUNK_BYTES", str(6 << 20))          # ~3000 pairs per chunk: several slots
+    debug_switches(monkeypatch, align_chunk_bytes=6 << 20)          # ~3000 pairs per chunk: several slots
     R, F, n = 150, 500, 20011
     reads, refs = synth.make_pairs(n, R, F, seed=21, n_run_frac=0.05, short_frac=0.08, lowercase_frac=0.05)
     AL = R + F

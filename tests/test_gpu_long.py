@@ -8,14 +8,14 @@ import pytest
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
 
-from conftest import band_constants
+from conftest import band_constants, debug_switches
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
 def forced_long(monkeypatch):
-    monkeypatch.setenv("VALIGN_HIP_FORCE_LONG", "1")
+    debug_switches(monkeypatch, force_long=1)
 
 
 @pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 1), (160, 64, 50, 2), (161, 700, 33, 3),
@@ -205,7 +205,7 @@ def test_largest_shape_the_abi_allows():
 def test_long_path_over_many_staging_chunks(forced_long, monkeypatch):
     """Host-pointer calls cycle through the pinned slots; strip kernels share one boundary-row scratch,
     so their chunks must run back to back on one stream -- eight chunks against the oracle."""
-    monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(256 << 10))       # 1024-pair chunks
+    debug_switches(monkeypatch, chunk_bytes=256 << 10)       # 1024-pair chunks
     R, F, blk = 330, 420, 2048
     r0, f0 = synth.make_pairs(blk, R, F, seed=31, indel_rate=0.01, n_run_frac=0.02, short_frac=0.05)
     reads, refs = np.tile(r0, (4, 1)), np.tile(f0, (4, 1))
@@ -417,9 +417,9 @@ def test_nw_alignments_on_int32_cells_where_int16_would_wrap():
                                          (2049, 300, 7, 76), (3000, 3500, 6, 77)])
 @pytest.mark.parametrize("gaps", [(-3, -3), (-2, -4)])
 def test_int32_alignment_cells_forced(monkeypatch, R, F, n, seed, gaps):
-    """The int32 strip kernel on shapes where int16 suffices (VALIGN_HIP_WIDE_ALIGN): identical to the int16 kernels'
+    """The int32 strip kernel on shapes where int16 suffices (VALIGN_HIP_DEBUG wide_align): identical to the int16 kernels'
     alignments and to the oracle -- one strip and many, odd pair counts, padding, invalid bases moving the end cell."""
-    monkeypatch.setenv("VALIGN_HIP_WIDE_ALIGN", "1")
+    debug_switches(monkeypatch, wide_align=1)
     reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.1, short_frac=0.15, lowercase_frac=0.05, junk_frac=0.05)
     sc = cpu_ref.Scoring.make(2, -1, gaps[0], gaps[1])
     with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=gaps[0], score_gap_ref=gaps[1], num_threads=3) as hip:

@@ -11,14 +11,14 @@ import pytest
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
 
-from conftest import ref_kernel
+from conftest import ref_kernel, debug_switches
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
 def small_bins(monkeypatch):
-    monkeypatch.setenv("VALIGN_HIP_RAGGED_MIN", "64")      # read at engine creation: many bins at test sizes
+    debug_switches(monkeypatch, ragged_min=64)      # read at engine creation: many bins at test sizes
 
 
 CASES = [
@@ -165,7 +165,7 @@ def test_ragged_device_resident_batch(small_bins, alg, R, F, n):
 def test_ragged_chunks_of_the_pipeline(small_bins, monkeypatch, packing):
     """Several chunks in flight: every chunk is classified while the host gathers the next one and swept one iteration
     later; affine scoring, both modes, 4-bit classes and ASCII across PCIe."""
-    monkeypatch.setenv("VALIGN_HIP_CHUNK_BYTES", str(1 << 20))          # ~1,600 pairs of 150 x 500 per chunk
+    debug_switches(monkeypatch, chunk_bytes=1 << 20)          # ~1,600 pairs of 150 x 500 per chunk
     R, F, n = 150, 500, 23017
     reads, refs = synth.make_ragged_pairs(n, R, F, seed=53, n_run_frac=0.03, short_frac=0.02, junk_frac=0.02)
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, open_read=-5, ext_read=-1, open_ref=-5, ext_ref=-1)

@@ -9,7 +9,7 @@ import pytest
 from oracle import cpu_ref
 from versalignlib_amd import build, hipkernel, host, synth
 
-from conftest import ref_kernel
+from conftest import ref_kernel, debug_switches
 
 pytestmark = pytest.mark.gpu
 
@@ -79,7 +79,7 @@ def test_affine_scores(R, F, n, seed, aff):
                 assert np.array_equal(got, lin)
 
 
-@pytest.mark.parametrize("geom", [(8, 20), (16, 10), (16, 12), (32, 8), (64, 12)])
+@pytest.mark.parametrize("geom", [(16, 10), (16, 12), (32, 8), (32, 10), (64, 8), (64, 12)])
 def test_every_geometry_agrees(geom):
     """The same batch through forced kernel geometries (lanes per pair group, rows per lane)."""
     R, F, n = 150, 500, 203
@@ -145,7 +145,7 @@ def test_full_size_properties_config2(monkeypatch, cells):
     and the first block must equal the oracle; NW variant as well."""
     import torch
     if cells == "int16":
-        monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+        debug_switches(monkeypatch, no_f16=1)
     R, F, blk, reps = 150, 500, 4096, 256
     reads, refs = synth.make_pairs(blk, R, F, seed=53, indel_rate=0.01)
     aff = (-5, -1, -5, -1)
@@ -259,9 +259,9 @@ def test_half_float_and_int16_forms_agree(monkeypatch, aff):
     osc = cpu_ref.Scoring.make(2, -1, -3, -3, **kw)
     d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
     fast = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **kw))
-    monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+    debug_switches(monkeypatch, no_f16=1)
     plain = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **kw))
-    monkeypatch.delenv("VALIGN_HIP_NO_F16")
+    debug_switches(monkeypatch, no_f16=None)
     for opt in (host.SW, host.NW):
         assert fast.describe(opt)["score_cells"] == "f16" and plain.describe(opt)["score_cells"] == "int16"
         a = fast.score_device(opt, d_reads, d_refs).cpu().numpy()
@@ -274,14 +274,14 @@ def test_half_float_and_int16_forms_agree(monkeypatch, aff):
 
 def test_small_calls_run_on_the_pinned_staging_directly(monkeypatch):
     """Calls of a few hundred KB skip the chunk pipeline: the kernels read the gathered sequences out of pinned host
-    memory and (scores) write their results there.  Same results as the pipeline, which VALIGN_HIP_DIRECT_BYTES=0 forces."""
+    memory and (scores) write their results there.  Same results as the pipeline, which VALIGN_HIP_DEBUG direct_bytes=0 forces."""
     R, F, n = 64, 128, 1000                                       # BASELINE configs[0]
     reads, refs = synth.make_pairs(n, R, F, seed=5, indel_rate=0.03, n_run_frac=0.05, short_frac=0.1)
     exp = [cpu_ref.score(opt, reads, refs, threads=8) for opt in (0, 1)]
     exp_rows = [cpu_ref.align(opt, reads, refs, threads=8) for opt in (0, 1)]
     for direct in (True, False):
         if not direct:
-            monkeypatch.setenv("VALIGN_HIP_DIRECT_BYTES", "0")
+            debug_switches(monkeypatch, direct_bytes=0)
         eng = hipkernel.Engine(R, F)
         for opt in (0, 1):
             assert np.array_equal(eng.score_host(opt, reads, refs, threads=2), exp[opt])
@@ -333,7 +333,7 @@ def test_nw_half_float_kernel_serves_two_different_gap_scores(monkeypatch):
     assert fast.describe(host.NW)["score_cells"] == "f16" and fast.describe(host.SW)["score_cells"] == "int16"
     assert np.array_equal(fast.score_device(host.NW, d_reads, d_refs).cpu().numpy(), exp)
     fast.close()
-    monkeypatch.setenv("VALIGN_HIP_NO_F16", "1")
+    debug_switches(monkeypatch, no_f16=1)
     plain = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -2, -4))
     assert plain.describe(host.NW)["score_cells"] == "int16"
     assert np.array_equal(plain.score_device(host.NW, d_reads, d_refs).cpu().numpy(), exp)

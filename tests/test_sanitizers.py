@@ -33,7 +33,9 @@ def test_host_pipeline_under_sanitizers(tmp_path, name, flags, env):
 
 
 def test_engine_uses_the_tested_header():
-    """hip_engine.hip.h must run THIS code (not a private copy of it) on its host threads."""
-    text = open(os.path.join(CSRC, "hip_engine.hip.h")).read()
+    """The engine must run THIS code (not a private copy of it) on its host threads."""
+    text = open(os.path.join(CSRC, "engine.hip.h")).read()
     assert '#include "host_pipeline.h"' in text
     assert "class WorkerPool" not in text and "packer_.gather(" in text and "packer_.scatter(" in text
+    for unit in ("engine_core.hip", "engine_score.hip", "engine_long.hip", "engine_align.hip"):
+        assert "class WorkerPool" not in open(os.path.join(CSRC, unit)).read()

@@ -1,16 +1,14 @@
 #!/bin/bash
-# A/B of the banded block chain on the GPU box: tests of the chain, then BASELINE config 5's per-GPU share at the LDS paddings of $PADS
-# (VALIGN_HIP_BAND_LDS_PAD: fewer waves per CU).  Output under gpurun_out/.
+# The banded block chain on the GPU box: its tests, then BASELINE config 5's per-GPU share (bench.py --workload long).
+# Output under gpurun_out/<tag>_band_*.
 set -o pipefail
 mkdir -p gpurun_out
 tag=${1:-r04}
 timeout -k 10 600 python -m pytest tests/test_gpu_band.py -x -q > gpurun_out/${tag}_band_tests.log 2>&1 || { tail -30 gpurun_out/${tag}_band_tests.log; exit 1; }
 tail -3 gpurun_out/${tag}_band_tests.log
-for c in ${PADS:-0}; do
-  VALIGN_HIP_BAND_LDS_PAD=$c timeout -k 10 300 python bench.py --workload long --steps 6 --warmup 2 --no-cpu > gpurun_out/${tag}_band_c$c.json 2> gpurun_out/${tag}_band_c$c.err || { tail -20 gpurun_out/${tag}_band_c$c.err; exit 1; }
-  python - <<PY
+timeout -k 10 300 python bench.py --workload long --steps 6 --warmup 2 --no-cpu > gpurun_out/${tag}_band.json 2> gpurun_out/${tag}_band.err || { tail -20 gpurun_out/${tag}_band.err; exit 1; }
+python - <<PY
 import json
-l = json.loads(open("gpurun_out/${tag}_band_c$c.json").read().strip().splitlines()[-1])
-print("lds_pad=$c", "ms_per_step", l["ms_per_step"], "value", l["value"], "waves_per_cu", l["roofline"].get("band_waves_per_cu"), "lds", l["roofline"].get("band_lds_per_wave"))
+l = json.loads(open("gpurun_out/${tag}_band.json").read().strip().splitlines()[-1])
+print("ms_per_step", l["ms_per_step"], "value", l["value"], "waves_per_cu", l["roofline"].get("band_waves_per_cu"), "lds", l["roofline"].get("band_lds_per_wave"))
 PY
-done

@@ -47,9 +47,4 @@ echo "sweeps done"
 bash tools/pmc_long.sh long_lin > $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_lin 65536 > $OUT/pmc_long.json
 bash tools/pmc_long.sh long_aff --affine 1 >> $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_aff 65536 > $OUT/pmc_long_affine.json
 echo "long pmc done"
-{ echo "# tools/microbench/bin/host_alloc <pairs> <threads> <mode 0 plain / 1 arena primed / 2 allocate first>: 2n new char[650] + copy, caller frees";
-  for m in 0 1 2; do ./tools/microbench/bin/host_alloc 1048576 16 $m 3; done;
-  echo "# the same with MALLOC_TOP_PAD_=268435456 (what the plugin's default host_malloc_tuning = 2 sets through mallopt): arenas grow in 256 MB steps";
-  MALLOC_TOP_PAD_=268435456 ./tools/microbench/bin/host_alloc 1048576 16 0 3;
-  echo "# nproc / cpu.max / transparent_hugepage"; nproc; cat /sys/fs/cgroup/cpu.max; cat /sys/kernel/mm/transparent_hugepage/enabled; } > $OUT/host_alloc.txt 2>&1
 echo "all done"

@@ -1,9 +1,9 @@
 #!/bin/bash
 # PMC passes over the alignment path (developer tool; run on the GPU box).
-# VALIGN_HIP_NO_OVERLAP: one fill and one traceback dispatch per million pairs (the default schedule cuts the batch
+# VALIGN_HIP_DEBUG=no_overlap: one fill and one traceback dispatch per million pairs (the default schedule cuts the batch
 # 7/8 + 1/8 and per-dispatch means would mix the two sizes).
 set -u
-export VALIGN_HIP_NO_OVERLAP=1
+export VALIGN_HIP_DEBUG=no_overlap
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp

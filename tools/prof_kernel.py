@@ -27,10 +27,9 @@ def main():
         int16_cells = gap.endswith("16")
         gap = gap[:-2] if int16_cells else gap
         sc = hipkernel.Scoring.make(2, -1, -3, -3, **(bench.AFFINE if gap == "affine" else {}))
-        if int16_cells:
-            os.environ["VALIGN_HIP_NO_F16"] = "1"
         eng = hipkernel.Engine(bench.R, bench.F, sc, group_lanes=G, rows_per_lane=K)
-        os.environ.pop("VALIGN_HIP_NO_F16", None)
+        if int16_cells:
+            eng.set_half_float_cells(0)
         for _ in range(a.reps):
             eng.score_device(0 if alg == "sw" else 1, reads, refs, out)
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """score_alignments(SW, affine) through the plugin ABI on a mixed-length batch (1,048,576 pairs of 150 x 500, prefixes of
-10-100 %): ragged_batching 0 / 2 against the staging chunk size (VALIGN_HIP_CHUNK_BYTES).  Run on the GPU box."""
+10-100 %): ragged_batching 0 / 2 against the staging chunk size (VALIGN_HIP_DEBUG chunk_bytes).  Run on the GPU box."""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ keys = dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref
 for rnd in range(2):
     for mb in (48, 96, 192, 384):
         for mode in (0, 2):
-            os.environ["VALIGN_HIP_CHUNK_BYTES"] = str(mb << 20)
+            os.environ["VALIGN_HIP_DEBUG"] = "chunk_bytes=%d" % (mb << 20)
             with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=threads, ragged_batching=mode, **keys) as k:
                 k.score_alignments(0, reads, refs, scattered=True)
                 best = min(k.score_alignments(0, reads, refs, scattered=True)[1] for _ in range(6))

@@ -26,11 +26,12 @@ if SANITIZED_DIR:
     HOST_LIB = os.path.join(SANITIZED_DIR, "libvalignhost.so")
     BENCH_CLI = os.path.join(SANITIZED_DIR, "valign-bench")
 
-HIP_SOURCES = ["hip_plugin.hip"]
+HIP_SOURCES = ["hip_plugin.hip", "engine_core.hip", "engine_score.hip", "engine_long.hip", "engine_align.hip"]
 HIP_KERNEL_PART = "kernel_part.hip"          # compiled once per part (kernel_instances.hip.h), in parallel
-HIP_KERNEL_PARTS = 7
-HIP_DEPS = ["hip_plugin.hip", "kernel_part.hip", "kernel_instances.hip.h", "dp_kernels.hip.h", "trace_kernels.hip.h",
-            "long_kernels.hip.h", "strip_kernels.hip.h", "hip_engine.hip.h", "host_pipeline.h", "band_kernels.hip.h", "pack_kernels.hip.h", "ragged_kernels.hip.h"]
+HIP_KERNEL_PARTS = 6
+# every header (a unit is rebuilt when its own source or any header changes; the kernel parts only look at KERNEL_PART_DEPS)
+HIP_HEADERS = ["kernel_instances.hip.h", "dp_kernels.hip.h", "trace_kernels.hip.h", "long_kernels.hip.h", "strip_kernels.hip.h",
+               "engine.hip.h", "host_runtime.hip.h", "host_pipeline.h", "band_kernels.hip.h", "pack_kernels.hip.h", "ragged_kernels.hip.h"]
 OBJ = os.path.join(PKG, "build")             # intermediate objects (git-ignored)
 HOST_SOURCES = ["valign_host.cpp"]
 
@@ -86,15 +87,16 @@ def build_hip(force=False, extra_flags=(), jobs=None):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(INCLUDE, h) for h in ("valign_hip.h", "versalign_plugin_abi.h")]
-    all_deps = [os.path.join(CSRC, s) for s in HIP_DEPS] + headers
+    all_deps = [os.path.join(CSRC, s) for s in HIP_HEADERS] + headers
     part_deps = [os.path.join(CSRC, s) for s in KERNEL_PART_DEPS]
     flags = list(extra_flags)
     stamp = os.path.join(OBJ, "flags.txt")             # objects built with other flags are stale
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
-    common = [hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-pthread", "-Wall",
+    common = [hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-pthread", "-Wall", "-fvisibility=hidden", "-fvisibility-inlines-hidden",
+              "--offload-compress",        # zstd-compressed code objects: 13.4 -> ~4 MB on disk, unpacked by the runtime at load
               "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC] + flags
-    units = [(os.path.join(CSRC, src), os.path.join(OBJ, os.path.splitext(src)[0] + ".o"), [], all_deps) for src in HIP_SOURCES]
+    units = [(os.path.join(CSRC, src), os.path.join(OBJ, os.path.splitext(src)[0] + ".o"), [], [os.path.join(CSRC, src)] + all_deps) for src in HIP_SOURCES]
     units += [(os.path.join(CSRC, HIP_KERNEL_PART), os.path.join(OBJ, "kernel_part%d.o" % i), ["-DVALIGN_PART=%d" % i], part_deps)
               for i in range(HIP_KERNEL_PARTS)]
     todo = [u for u in units if force or _newer(u[1], u[3])]

@@ -17,7 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "hip_engine.hip.h"
+#include "engine.hip.h"
 
 #define VALIGN_EXPORT __attribute__((visibility("default")))
 
@@ -196,6 +196,7 @@ public:
                 // unless the host says otherwise -- larger batches simply run in more chunks
                 e->set_pointer_scratch_cap_mb(opt_param("pointer_scratch_cap_mb", 0));
                 if (Parameters.has_key("host_packing")) e->set_host_packing(Parameters.param_int("host_packing"));
+                if (Parameters.has_key("half_float_cells")) e->set_half_float_cells(Parameters.param_int("half_float_cells"));
                 if (d == 0) engine_ = std::move(e);
                 else more_.push_back(std::move(e));
             }
@@ -445,6 +446,14 @@ VALIGN_EXPORT int valign_hip_set_host_packing(valign_hip_engine *e, int mode) {
         return 1;
     }
     return flat_guard([&] { e->impl->set_host_packing(mode); });
+}
+
+VALIGN_EXPORT int valign_hip_set_half_float_cells(valign_hip_engine *e, int mode) {
+    if (!e) {
+        g_last_error = "null engine";
+        return 1;
+    }
+    return flat_guard([&] { e->impl->set_half_float_cells(mode); });
 }
 
 VALIGN_EXPORT int valign_hip_set_pointer_scratch_cap_mb(valign_hip_engine *e, long long mb) {

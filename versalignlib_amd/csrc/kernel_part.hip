@@ -14,21 +14,20 @@
 
 namespace valign {
 
-#define VALIGN_DEFINE(G, K) VALIGN_GEOMETRY_KERNELS(template, G, K)
+#define VALIGN_DEFINE_FULL(G, K) VALIGN_FAST_KERNELS(template, G, K) VALIGN_FALLBACK_KERNELS(template, G, K)
+#define VALIGN_DEFINE_FAST(G, K) VALIGN_FAST_KERNELS(template, G, K)
 #if VALIGN_PART == 0
-VALIGN_GEOMETRIES_PART0(VALIGN_DEFINE)
+VALIGN_PART0(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #elif VALIGN_PART == 1
-VALIGN_GEOMETRIES_PART1(VALIGN_DEFINE)
+VALIGN_PART1(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #elif VALIGN_PART == 2
-VALIGN_GEOMETRIES_PART2(VALIGN_DEFINE)
+VALIGN_PART2(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #elif VALIGN_PART == 3
-VALIGN_GEOMETRIES_PART3(VALIGN_DEFINE)
+VALIGN_PART3(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #elif VALIGN_PART == 4
-VALIGN_GEOMETRIES_PART4(VALIGN_DEFINE)
+VALIGN_PART4(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #elif VALIGN_PART == 5
-VALIGN_GEOMETRIES_PART5(VALIGN_DEFINE)
-#elif VALIGN_PART == 6
-VALIGN_GEOMETRIES_PART6(VALIGN_DEFINE)
+VALIGN_PART5(VALIGN_DEFINE_FULL, VALIGN_DEFINE_FAST)
 #else
 #error "VALIGN_PART out of range"
 #endif

@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned expand_classes4(unsigned x) {
     return __builtin_amdgcn_perm(0x00004E47u, 0x43544100u, sel & 0x07070707u);
 }
 
-#ifndef VALIGN_KERNEL_PART_TU      // not a template: defined once, in the plugin's main translation unit
+#ifdef VALIGN_TU_SCORE      // not templates: defined once, in engine_score.hip
 // Even `len`: the batch is one flat nibble stream (row boundaries fall on byte boundaries) -- a thread expands 8
 // packed bytes into 16 output bytes, 8-byte coalesced loads, 16-byte coalesced stores.
 __global__ void __launch_bounds__(256)

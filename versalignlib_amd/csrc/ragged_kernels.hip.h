@@ -67,7 +67,7 @@ struct RaggedUnpermuteArgs {
     long long n;
 };
 
-#ifndef VALIGN_KERNEL_PART_TU
+#ifdef VALIGN_TU_SCORE      // not templates: defined once, in engine_score.hip
 
 __device__ __forceinline__ bool ragged_is_acgt(unsigned ch) {
     const unsigned u = ch & 0xDFu, t = u - 'A';                       // bytes >= 0x80 keep bit 7: never a letter
@@ -224,6 +224,6 @@ __global__ void __launch_bounds__(256) ragged_unpermute_kernel(const RaggedUnper
     if (i < a.n) a.scores[i] = a.packed[a.pos[i]];
 }
 
-#endif  // VALIGN_KERNEL_PART_TU
+#endif  // VALIGN_TU_SCORE
 
 }  // namespace valign

@@ -45,7 +45,7 @@ struct StripArgs {
     short open_read, ext_read, open_ref, ext_ref;     // affine
 };
 
-#ifndef VALIGN_KERNEL_PART_TU
+#ifdef VALIGN_TU_ALIGN      // not a template: defined once, in engine_align.hip
 // First position of each read / ref whose base class is 0 (else R / F): one wave per pair.
 __global__ void __launch_bounds__(64)
 first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int R, int F, int *out, int n_is_invalid) {

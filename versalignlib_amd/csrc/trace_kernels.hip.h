@@ -255,7 +255,7 @@ __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *p
     out[3] = (short)(AL - 1);
 }
 
-#ifndef VALIGN_KERNEL_PART_TU      // not a template: defined once, in the plugin's main translation unit
+#ifdef VALIGN_TU_ALIGN      // not a template: defined once, in engine_align.hip
 // One lane per pair over the HBM pointer scratch.
 __global__ void __launch_bounds__(256)
 traceback_kernel(const TraceArgs a) {

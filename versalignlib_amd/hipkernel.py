@@ -63,6 +63,7 @@ def lib():
         L.valign_hip_set_band_width.argtypes = [vp, ctypes.c_int]
         L.valign_hip_set_pointer_scratch_cap_mb.argtypes = [vp, ctypes.c_longlong]
         L.valign_hip_set_host_packing.argtypes = [vp, ctypes.c_int]
+        L.valign_hip_set_half_float_cells.argtypes = [vp, ctypes.c_int]
         L.valign_hip_host_register.argtypes = [vp, ctypes.c_ulonglong]
         L.valign_hip_host_unregister.argtypes = [vp]
         L.valign_hip_set_score_width.argtypes = [vp, ctypes.c_int]
@@ -81,7 +82,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
     "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
-    "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_host_packing", "valign_hip_host_register", "valign_hip_host_unregister", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
+    "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_host_packing", "valign_hip_set_half_float_cells", "valign_hip_host_register", "valign_hip_host_unregister", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
 
@@ -130,6 +131,11 @@ class Engine:
     def set_host_packing(self, mode):
         """Host-pointer score path: 1 = 4-bit base classes across PCIe (default), 0 = raw ASCII."""
         if lib().valign_hip_set_host_packing(self._h, int(mode)) != 0:
+            raise HipKernelError(_err())
+
+    def set_half_float_cells(self, mode):
+        """score path: 1 = half-float cells where exact (default), 0 = integer cells only (identical scores)."""
+        if lib().valign_hip_set_half_float_cells(self._h, int(mode)) != 0:
             raise HipKernelError(_err())
 
     def set_score_width(self, bits):
