@@ -102,6 +102,27 @@ void round_trip(int R, int F, long long n, int threads) {
         }
         expect(ok, "Alignment scatter n=" + std::to_string(n));
     }
+    // packed staging (what the device sends since round 4): every row from column `col` on only -- col: the smallest start of
+    // the chunk rounded down to 64; the scatter unpacks and writes the zeros in front
+    {
+        size_t col = AL;
+        for (long long i = 0; i < n; ++i) col = std::min(col, (size_t)st_idx[(size_t)i * 4]);
+        col &= ~(size_t)63;
+        const size_t W = AL - col;
+        std::vector<uint8_t> packed((size_t)n * 2 * W + 1, 0x77);
+        for (long long r = 0; r < 2 * n; ++r) memcpy(packed.data() + (size_t)r * W, st_rows.data() + (size_t)r * AL + col, W);
+        std::fill(flat_rows.begin(), flat_rows.end(), (uint8_t)0xEE);
+        packer.scatter(valign::FlatSink{flat_rows.data(), flat_idx.data(), AL}, n, packed.data(), st_idx.data(), threads, col);
+        expect(memcmp(flat_rows.data(), st_rows.data(), (size_t)n * 2 * AL) == 0 && flat_rows[(size_t)n * 2 * AL] == 0xEE,
+               "flat scatter from packed rows");
+        std::vector<FakeAlignment> out((size_t)n);
+        packer.scatter(out.data(), n, packed.data(), st_idx.data(), threads, col);
+        bool ok = true;
+        for (long long i = 0; i < n && ok; ++i)
+            ok = memcmp(out[(size_t)i].read, st_rows.data() + (size_t)i * 2 * AL, AL) == 0 &&
+                 memcmp(out[(size_t)i].ref, st_rows.data() + (size_t)i * 2 * AL + AL, AL) == 0;
+        expect(ok, "Alignment scatter from packed rows");
+    }
     for (long long i = 0; i < n; ++i) {
         delete[] reads[(size_t)i];
         delete[] refs[(size_t)i];

@@ -479,3 +479,41 @@ def test_host_pointer_alignments_of_a_large_batch():
         erows, eidx = cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, -3, -3), threads=8)
         assert np.array_equal(idx[0], eidx) and np.array_equal(rows[0], erows)
     eng.close()
+
+
+@pytest.mark.parametrize("R,F", [(75, 230), (100, 300), (200, 640), (700, 900)])
+def test_calls_that_need_a_fallback_kernel_are_replanned_onto_a_full_geometry(monkeypatch, R, F):
+    """Round 4 compiles the equality-test / SSE-policy / asymmetric-affine fill kernels for six "full" geometries only
+    (kernel_instances.hip.h).  These shapes plan onto geometries that carry the fast set alone (8x10, 16x8, 32x8, 64x12):
+    a call that needs one of the other kernels must be re-planned (Engine::align_plan_for) and return the oracle's rows."""
+    n = 257
+    reads, refs = _data(R, F, n, 300 + R)
+    eng = hipkernel.Engine(R, F)
+    d = eng.describe(0, n)
+    eng.close()
+    assert (d["group_lanes"], d["rows_per_lane"]) in ((8, 10), (16, 8), (32, 8), (64, 12)), d      # a fast-only geometry
+    lin = cpu_ref.Scoring.make()
+    for opt in (0, 1):
+        # SSE2 / AVX2 tie-breaks
+        with host.Plugin(build.HIP_PLUGIN, R, F, traceback_policy=1) as hip:
+            _assert_same(hip.compute_alignments(opt, reads, refs, normalise=False),
+                         cpu_ref.align(opt, reads, refs, lin, threads=8, policy="sse"), (R, F, opt, "sse"))
+        # affine scores that differ by direction
+        aff = cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -4, -2)
+        keys = dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-4, score_gap_extend_ref=-2)
+        with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
+            _assert_same(hip.compute_alignments(opt, reads, refs, normalise=False),
+                         cpu_ref.align(opt, reads, refs, aff, threads=8, affine=True), (R, F, opt, "affine_asym"))
+    # equality-test kernels (what a scoring beyond the tagged cells' headroom takes), forced by the debug switch
+    debug_switches(monkeypatch, no_tag=1)
+    with host.Plugin(build.HIP_PLUGIN, R, F) as hip:
+        for opt in (0, 1):
+            _assert_same(hip.compute_alignments(opt, reads, refs, normalise=False),
+                         cpu_ref.align(opt, reads, refs, lin, threads=8), (R, F, opt, "no_tag"))
+    # ... and a scoring that really leaves the headroom: match 60 -> 4 * 75 * 60 > 32000 / 4
+    if R <= 100:
+        big = cpu_ref.Scoring.make(60, -40, -50, -50)
+        debug_switches(monkeypatch, no_tag=None)
+        with host.Plugin(build.HIP_PLUGIN, R, F, score_match=60, score_mismatch=-40, score_gap_read=-50, score_gap_ref=-50) as hip:
+            _assert_same(hip.compute_alignments(0, reads, refs, normalise=False),
+                         cpu_ref.align(0, reads, refs, big, threads=8), (R, F, "big scores"))

@@ -93,15 +93,23 @@ def test_flat_results_go_straight_into_registered_buffers(monkeypatch):
                 rows[:] = 0xEE
                 idx[:] = -1
                 eng.align_host(opt, reads, refs, threads=6, out=(rows, idx))
-                assert eng.describe(opt, n)["direct_out"] == 1
+                d = eng.describe(opt, n)
+                assert d["direct_out"] == 1
                 assert np.array_equal(idx, exp_idx) and np.array_equal(rows, exp_rows), (affine, opt)
+                assert d["full_row_mb"] > 0 and d["d2h_row_mb"] == d["full_row_mb"]        # whole rows, straight from the copy engine
                 # a part of the registered buffers works too (the call covers fewer pairs than were registered)
                 rows[:] = 0xEE
                 eng.align_host(opt, reads[:7001], refs[:7001], threads=6, out=(rows[:7001], idx[:7001]))
                 assert eng.describe(opt, n)["direct_out"] == 1
                 assert np.array_equal(rows[:7001], exp_rows[:7001]) and (rows[7001:] == 0xEE).all()
                 plain = eng.align_host(opt, reads, refs, threads=6)                     # fresh, unregistered buffers
-                assert eng.describe(opt, n)["direct_out"] == 0
+                d = eng.describe(opt, n)
+                assert d["direct_out"] == 0
+                # staged: only the columns that hold strings cross PCIe, packed on the device -- a third of the rows' bytes
+                # for Smith-Waterman alignments of 150 bp reads in 650-byte rows; the scatter writes the zeros in front
+                assert 0 < d["d2h_row_mb"] <= d["full_row_mb"]
+                if opt == host.SW:
+                    assert d["d2h_row_mb"] < 0.45 * d["full_row_mb"], d
                 assert np.array_equal(plain[1], exp_idx) and np.array_equal(plain[0], exp_rows)
             eng.close()
     finally:

@@ -177,7 +177,7 @@ public:
         if (!env) return;
         static const char *const known[] = {"no_sym", "no_tag", "no_f16", "no_fused", "no_prof_key", "no_overlap", "no_band_chain",
                                             "force_long", "wide_align", "no_direct_out", "ragged_min", "chunk_bytes",
-                                            "align_chunk_bytes", "direct_bytes", "scratch_cap_mb"};
+                                            "align_chunk_bytes", "direct_bytes", "scratch_cap_mb", "whole_rows"};
         std::string s(env);
         for (size_t at = 0; at <= s.size();) {
             const size_t end = std::min(s.find(',', at), s.size());
@@ -224,6 +224,7 @@ public:
         int packed = 0;                                      // 1: the sequences crossed PCIe as 4-bit classes
         int direct_out = 0;                                  // 1: results were copied straight into the caller's (registered) buffers
         int direct = 0;                                      // 1: small call, kernels worked on the pinned staging directly; 2: ... in one fused launch
+        double d2h_row_bytes = 0, full_row_bytes = 0;        // align_host: result-row bytes that crossed PCIe / that whole rows would have been
     };
 
     Engine(int device, int R, int F, const Scoring &sc, int force_g, int force_k);
@@ -383,6 +384,8 @@ public:
     struct WalkChain {
         int region;
         long long chunk_pairs;
+        int *min_start;             // device word: the traceback leaves the chunk's smallest readStart there (or nullptr)
+        uint8_t *packed;            // ... and the rows, packed to their columns from there on, go here (compact_rows_kernel)
     };
     hipEvent_t trace_done(int region) const { return trace_done_[region]; }
     struct FillChoice {
@@ -490,8 +493,8 @@ private:
 
     // gather / scatter between the caller's scattered blocks and the staging: host_pipeline.h (host-only, sanitizer-tested)
     template <typename Sink>
-    void scatter(Sink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
-        packer_.scatter(sink, cnt, rows, idx, threads);
+    void scatter(Sink sink, long long cnt, const uint8_t *rows, const short *idx, int threads, size_t first_col = 0) {
+        packer_.scatter(sink, cnt, rows, idx, threads, first_col);
     }
 
     void release_staging();
@@ -601,6 +604,7 @@ private:
     bool copy_engines_primed_ = false;
     std::unique_ptr<CopyIssuer> copy_issuer_;
     bool wide_align_ = dbg_.on("wide_align");         // NW alignments (linear gaps, default tie-breaks) on int32 cells always
+    bool whole_rows_ = dbg_.on("whole_rows");         // result rows cross PCIe whole (A/B of the device-side packing)
     bool no_direct_out_ = dbg_.on("no_direct_out");   // stage + scatter even into registered result buffers
     bool no_overlap_ = dbg_.on("no_overlap");   // tracebacks in stream order behind their fills
     long long scratch_cap_mb_ = dbg_.value("scratch_cap_mb", 0);   // small pointer scratch: chunked alignment batches in tests (key: pointer_scratch_cap_mb)
@@ -638,6 +642,9 @@ private:
     size_t first_bad_bytes_ = 0;
     uint8_t *h_rows_[kSlots] = {}, *d_rows_[kSlots] = {};
     short *h_idx_[kSlots] = {}, *d_idx_[kSlots] = {};
+    uint8_t *d_packed_rows_[kSlots] = {};                        // the chunk's rows without their all-zero leading columns
+    int *d_min_start_ = nullptr, *h_min_start_ = nullptr;       // per slot: first column of the chunk's rows that holds a string (device / pinned)
+    int start_col_[kSlots] = {};                                 // ... as the copy issuer used it (columns before it were not copied)
     hipEvent_t in_done_[kSlots] = {}, kernels_done_[kSlots] = {};   // align_host: H2D / kernels of the slot's chunk finished
 };
 

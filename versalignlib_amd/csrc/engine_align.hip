@@ -242,10 +242,20 @@ bool Engine::align_device(int opt, long long n, const uint8_t *d_reads, const ui
             hip_check(hipStreamWaitEvent(trace_stream_, fill_done_[part.region], 0), "hipStreamWaitEvent");
             walk_stream = trace_stream_;
             if (chain) hip_check(hipMemsetAsync(d_rows, 0, (size_t)n * 2 * AL, trace_stream_), "hipMemsetAsync(rows)");
+            if (chain && chain->min_start) {
+                hip_check(hipMemsetD32Async((hipDeviceptr_t)chain->min_start, AL, 1, trace_stream_), "hipMemsetD32Async(first column)");
+                t.min_start = chain->min_start;
+            }
         }
         hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256),
                                   targs, 0, walk_stream),
                   "hipLaunchKernel(traceback_kernel)");
+        if (chain && chain->min_start && chain->packed) {
+            CompactArgs c{t.rows, chain->packed, chain->min_start, 2 * cnt, AL};
+            void *cargs[] = {&c};
+            hip_check(hipLaunchKernel((const void *)&compact_rows_kernel, dim3((unsigned)(2 * cnt)), dim3(256), cargs, 0, walk_stream),
+                      "hipLaunchKernel(compact_rows_kernel)");
+        }
         if (helper) {
             hip_check(hipEventRecord(trace_done_[part.region], trace_stream_), "hipEventRecord");
             region_used[part.region] = true;
@@ -525,13 +535,17 @@ void Engine::align_host(int opt, int n, const char *const *reads, const char *co
     short *direct_idx = nullptr;
     if (!no_direct_out_) flat_destination(alignments, n, direct_rows, direct_idx);
     host_stats_.direct_out = direct_rows ? 1 : 0;
+    // Result rows are right-justified strings behind zeros: on the staged paths only the columns from the chunk's smallest
+    // readStart on cross PCIe, packed on the device (compact_rows_kernel; 0.42 instead of 1.36 GB per million pairs of
+    // 150 x 500) -- the scatter unpacks them and writes the zeros in front, as it always did.  A registered flat
+    // destination still receives whole rows straight from the copy engine: there the zeros would be the host's to write.
     auto drain = [&](int s) {
         if (slot_pending_[s] <= 0) return;
-        if (!direct_rows) {
-            const auto t0 = std::chrono::steady_clock::now();
-            scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads);
-            host_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
-        }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!direct_rows) scatter(alignments + slot_begin_[s], slot_pending_[s], h_rows_[s], h_idx_[s], threads, (size_t)start_col_[s]);
+        host_stats_.drain_ms += ms_between(t0, std::chrono::steady_clock::now());
+        host_stats_.d2h_row_bytes += (double)slot_pending_[s] * 2 * (AL - start_col_[s]);
+        host_stats_.full_row_bytes += (double)slot_pending_[s] * 2 * AL;
         slot_pending_[s] = 0;
     };
     int slot = 0;
@@ -573,15 +587,26 @@ void Engine::align_host(int opt, int n, const char *const *reads, const char *co
         hip_check(hipEventRecord(in_done_[slot], copy_in), "hipEventRecord");
         hip_check(hipStreamWaitEvent(kernels, in_done_[slot], 0), "hipStreamWaitEvent");
         // the walk of this chunk runs on the helper stream beside the fill of the next one (two scratch regions)
-        const WalkChain chain{(int)(chunk_no & 1), chunk};
+        const bool packed = !direct_rows && !whole_rows_;
+        const WalkChain chain{(int)(chunk_no & 1), chunk, packed ? d_min_start_ + slot : nullptr, packed ? d_packed_rows_[slot] : nullptr};
         const bool chained = align_device(opt, cnt, d_reads_[slot], d_refs_[slot], d_rows_[slot], d_idx_[slot], kernels, &chain);
         hip_check(hipEventRecord(kernels_done_[slot], chained ? trace_stream_ : kernels), "hipEventRecord");      // the chunk's last kernel
         ++chunk_no;
         uint8_t *rows_to = direct_rows ? direct_rows + (size_t)begin * 2 * AL : h_rows_[slot];
         short *idx_to = direct_idx ? direct_idx + 4 * begin : h_idx_[slot];
         // SDMA, not a blit kernel beside the next fill: the copies are issued once the host has seen the kernels end
-        copy_issuer->submit(CopyIssuer::Job{kernels_done_[slot], {rows_to, idx_to}, {d_rows_[slot], d_idx_[slot]},
-                                            {(size_t)cnt * 2 * AL, sizeof(short) * 4 * (size_t)cnt}, copy_out, slot_done_[slot], slot});
+        CopyIssuer::Job job{kernels_done_[slot], {rows_to, idx_to}, {d_rows_[slot], d_idx_[slot]},
+                            {(size_t)cnt * 2 * AL, sizeof(short) * 4 * (size_t)cnt}, copy_out, slot_done_[slot], slot};
+        start_col_[slot] = 0;
+        if (chained && packed) {        // (the stream-order fallback -- row strips, a scratch too small for two regions -- copies whole rows)
+            job.src[0] = d_packed_rows_[slot];
+            job.d_min = d_min_start_ + slot;
+            job.h_min = h_min_start_ + slot;
+            job.row_bytes = AL;
+            job.rows = 2 * cnt;
+            job.col = &start_col_[slot];
+        }
+        copy_issuer->submit(job);
         slot_begin_[slot] = begin;
         slot_pending_[slot] = cnt;
     }
@@ -629,12 +654,18 @@ void Engine::release_trace_scratch() {
         if (h_idx_[s]) (void)hipHostFree(h_idx_[s]);
         if (d_rows_[s]) (void)hipFree(d_rows_[s]);
         if (d_idx_[s]) (void)hipFree(d_idx_[s]);
+        if (d_packed_rows_[s]) (void)hipFree(d_packed_rows_[s]);
+        d_packed_rows_[s] = nullptr;
         h_rows_[s] = nullptr;
         h_idx_[s] = nullptr;
         d_rows_[s] = nullptr;
         d_idx_[s] = nullptr;
     }
     align_staged_pairs_ = 0;
+    if (d_min_start_) (void)hipFree(d_min_start_);
+    if (h_min_start_) (void)hipHostFree(h_min_start_);
+    d_min_start_ = nullptr;
+    h_min_start_ = nullptr;
 }
 
 void Engine::ensure_trace_scratch(long long pairs, size_t bytes_per_pp, long long ppw, hipStream_t stream) {
@@ -674,6 +705,13 @@ void Engine::ensure_align_staging(long long pairs) {
         hip_check(hipHostMalloc((void **)&h_idx_[s], sizeof(short) * 4 * (size_t)pairs, hipHostMallocDefault), "hipHostMalloc");
         hip_check(hipMalloc((void **)&d_rows_[s], rows_cap), "hipMalloc");
         hip_check(hipMalloc((void **)&d_idx_[s], sizeof(short) * 4 * (size_t)pairs), "hipMalloc");
+        if (d_packed_rows_[s]) (void)hipFree(d_packed_rows_[s]);
+        d_packed_rows_[s] = nullptr;
+        hip_check(hipMalloc((void **)&d_packed_rows_[s], (size_t)pairs * 2 * AL + 64), "hipMalloc(packed rows)");
+    }
+    if (!d_min_start_) {
+        hip_check(hipMalloc((void **)&d_min_start_, sizeof(int) * kSlots), "hipMalloc(first columns)");
+        hip_check(hipHostMalloc((void **)&h_min_start_, sizeof(int) * kSlots, hipHostMallocDefault), "hipHostMalloc(first columns)");
     }
     align_staged_pairs_ = pairs;
 }

@@ -244,19 +244,33 @@ public:
         return std::max<long long>(64, (768ll << 10) / (2 * (long long)std::max<size_t>(AL, 1)));
     }
 
-    // staging -> the caller's contiguous buffers
-    void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads) {
-        const size_t AL = sink.AL;
+    // staging -> the caller's contiguous buffers.  Like the Alignment scatter below, only the strings are read out of the
+    // staging (both rows of a pair start at idx[0]); the zeros in front are written here -- the staging's columns before
+    // the chunk's first string are not even copied from the device any more (Engine::align_host).
+    // `first_col`: the staging holds every row from that column on only (rows of AL - first_col bytes: the device packed
+    // them before the copy, compact_rows_kernel); 0 = whole rows.  No string starts before it.
+    void scatter(FlatSink sink, long long cnt, const uint8_t *rows, const short *idx, int threads, size_t first_col = 0) {
+        const size_t AL = sink.AL, W = AL - first_col;
         for_ranges(threads, cnt, serial_below_for_rows(AL), [=](int, long long lo, long long hi) {
-            memcpy(sink.rows + (size_t)lo * 2 * AL, rows + (size_t)lo * 2 * AL, (size_t)(hi - lo) * 2 * AL);
+            for (long long i = lo; i < hi; ++i) {
+                size_t start = idx[4 * i + 0] > 0 ? (size_t)idx[4 * i + 0] : 0;
+                if (start > AL) start = AL;
+                if (start < first_col) start = first_col;       // (cannot happen: first_col <= every start)
+                const uint8_t *src = rows + (size_t)i * 2 * W;
+                uint8_t *dst = sink.rows + (size_t)i * 2 * AL;
+                memset(dst, 0, start);
+                memcpy(dst + start, src + (start - first_col), AL - start);
+                memset(dst + AL, 0, start);
+                memcpy(dst + AL + start, src + W + (start - first_col), AL - start);
+            }
             memcpy(sink.idx + 4 * lo, idx + 4 * lo, sizeof(short) * 4 * (size_t)(hi - lo));
         });
     }
 
     // staging -> the ABI's Alignment array: two fresh operator new[] rows per pair (the caller delete[]s them)
     template <typename AlignmentT>
-    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads) {
-        const size_t AL = (size_t)R_ + F_;
+    void scatter(AlignmentT *alignments, long long cnt, const uint8_t *rows, const short *idx, int threads, size_t first_col = 0) {
+        const size_t AL = (size_t)R_ + F_, W = AL - first_col;
         for_ranges(threads, cnt, serial_below_for_rows(AL), [=](int, long long lo, long long hi) {
             for (long long i = lo; i < hi; ++i) {
                 AlignmentT &a = alignments[i];
@@ -267,11 +281,12 @@ public:
                 // third of its bytes at 150 x 500 -- the zeros are written here.
                 size_t start = idx[4 * i + 0] > 0 ? (size_t)idx[4 * i + 0] : 0;
                 if (start > AL) start = AL;
-                const uint8_t *src = rows + (size_t)i * 2 * AL;
+                if (start < first_col) start = first_col;       // (cannot happen: first_col <= every start)
+                const uint8_t *src = rows + (size_t)i * 2 * W;
                 memset(a.read, 0, start);
-                memcpy(a.read + start, src + start, AL - start);
+                memcpy(a.read + start, src + (start - first_col), AL - start);
                 memset(a.ref, 0, start);
-                memcpy(a.ref + start, src + AL + start, AL - start);
+                memcpy(a.ref + start, src + W + (start - first_col), AL - start);
                 a.readStart = idx[4 * i + 0];
                 a.readEnd = idx[4 * i + 1];
                 a.refStart = idx[4 * i + 2];

@@ -20,6 +20,15 @@ public:
         hipStream_t stream;
         hipEvent_t done;            // recorded behind the copies
         int slot;
+        // Packed rows (align_host): src[0] holds `rows` rows of `row_bytes` bytes packed to their columns from `col` on --
+        // col = *d_min (the chunk's smallest readStart, left by the traceback) rounded down to 64, the packing done by
+        // compact_rows_kernel before `ready` fired.  rows * (row_bytes - col) bytes cross PCIe as one linear copy; col is
+        // left in *col for the host, which unpacks and owns the zeros in front.  d_min null: whole rows (bytes[0]).
+        const int *d_min = nullptr;
+        int *h_min = nullptr;       // pinned word the column travels through
+        int row_bytes = 0;
+        long long rows = 0;
+        int *col = nullptr;
     };
     explicit CopyIssuer(int device) : device_(device), thread_([this] { loop(); }) {}
     ~CopyIssuer() {
@@ -70,7 +79,20 @@ private:
             std::exception_ptr err;
             try {
                 hip_check(hipEventSynchronize(job.ready), "hipEventSynchronize(kernels of the chunk)");
-                for (int k = 0; k < 2; ++k)
+                int first = 0;
+                if (job.d_min && job.rows > 0) {
+                    hip_check(hipMemcpyAsync(job.h_min, job.d_min, sizeof(int), hipMemcpyDeviceToHost, job.stream), "D2H first column");
+                    hip_check(hipStreamSynchronize(job.stream), "hipStreamSynchronize");
+                    int c = *job.h_min;
+                    c = c < 0 ? 0 : (c > job.row_bytes ? job.row_bytes : c);
+                    c &= ~63;                                   // (first_copied_column of trace_kernels.hip.h)
+                    *job.col = c;
+                    if (c < job.row_bytes)
+                        hip_check(hipMemcpyAsync(job.dst[0], job.src[0], (size_t)job.rows * (size_t)(job.row_bytes - c), hipMemcpyDeviceToHost, job.stream),
+                                  "D2H result rows (packed columns)");
+                    first = 1;
+                }
+                for (int k = first; k < 2; ++k)
                     if (job.bytes[k])
                         hip_check(hipMemcpyAsync(job.dst[k], job.src[k], job.bytes[k], hipMemcpyDeviceToHost, job.stream), "D2H results");
                 hip_check(hipEventRecord(job.done, job.stream), "hipEventRecord");

@@ -77,6 +77,8 @@ struct TraceArgs {
     short open_read, ext_read, open_ref, ext_ref;
     int strip_rows;           // > 0: the read was swept in row strips of this many padded rows (strip_kernels.hip.h),
     long long strip_words;    //      each with its own region of the pointer stream, this many dwords apart
+    int *min_start;           // not null: receives the smallest readStart of the launch (atomicMin; the caller presets R + F) --
+                              // the host then copies only the columns from there on out of every row (Engine::align_host)
 };
 
 typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword access at any byte address
@@ -90,9 +92,9 @@ typedef unsigned __attribute__((aligned(1))) u32_any_align;   // global dword ac
 // kernel (align_fill_tag_kernel<..., FUSED>) the copy it keeps in LDS.
 template <bool BYTE_ROWS = false>      // BYTE_ROWS: everything the walk touches sits in LDS (fused kernel) -- explicit LDS reads,
                                        // one byte store per step (no dword at an odd LDS address)
-__device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *ptr_pair, long long ptr_words, int half,
-                                           const EndCell e, const uint8_t *read, const uint8_t *ref,
-                                           uint8_t *row_read, uint8_t *row_ref, short *out) {
+__device__ __forceinline__ int trace_walk(const TraceArgs &a, const unsigned *ptr_pair, long long ptr_words, int half,
+                                          const EndCell e, const uint8_t *read, const uint8_t *ref,
+                                          uint8_t *row_read, uint8_t *row_ref, short *out) {
     const int R = a.R, F = a.F, AL = R + F, K = a.K;
     const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;      // words per lane and block of steps
     const int half_shift = half * 16;
@@ -253,6 +255,7 @@ __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *p
     out[1] = (short)(AL - 1);
     out[2] = (short)(k + 1);
     out[3] = (short)(AL - 1);
+    return k + 1;                                       // readStart = refStart: where both rows' strings begin
 }
 
 #ifdef VALIGN_TU_ALIGN      // not a template: defined once, in engine_align.hip
@@ -260,17 +263,55 @@ __device__ __forceinline__ void trace_walk(const TraceArgs &a, const unsigned *p
 __global__ void __launch_bounds__(256)
 traceback_kernel(const TraceArgs a) {
     const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n) return;
     const int R = a.R, F = a.F, AL = R + F, K = a.K, G = a.G;
-    const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;
-    // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
-    const int ppw = 2 * (kWave / G);
-    const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
-    long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
-    if (a.strip_rows > 0) ptr_words += (long long)((R + a.pad_rows) / a.strip_rows - 1) * a.strip_words;   // ... of the last strip
-    uint8_t *row_read = a.rows + pair * 2 * AL;
-    trace_walk(a, ptr_pair, ptr_words, (int)(pair & 1), a.ends[pair], a.reads + pair * R, a.refs + pair * F, row_read,
-               row_read + AL, a.idx + pair * 4);
+    int start = AL;
+    if (pair < a.n) {
+        const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;
+        // pointer stream: [wave][block][lane of the wave][wpb]; this pair's group starts at lane (pair-of-pairs % groups) * G
+        const int ppw = 2 * (kWave / G);
+        const unsigned *ptr_pair = a.ptr + ((pair / ppw) * a.blocks8 * kWave + ((pair % ppw) >> 1) * G) * (long long)wpb;
+        long long ptr_words = ((long long)(a.blocks8 - 1) * kWave + G) * wpb;   // words from there to the end of the group's last block
+        if (a.strip_rows > 0) ptr_words += (long long)((R + a.pad_rows) / a.strip_rows - 1) * a.strip_words;   // ... of the last strip
+        uint8_t *row_read = a.rows + pair * 2 * AL;
+        start = trace_walk(a, ptr_pair, ptr_words, (int)(pair & 1), a.ends[pair], a.reads + pair * R, a.refs + pair * F, row_read,
+                           row_read + AL, a.idx + pair * 4);
+    }
+    if (a.min_start) {                                  // (uniform) the launch's smallest start: one atomic per wave
+#pragma unroll
+        for (int d = kWave / 2; d >= 1; d >>= 1) {
+            const int other = __shfl_xor(start, d, kWave);
+            start = other < start ? other : start;
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0 && start < AL) atomicMin(a.min_start, start);
+    }
+}
+
+// Result rows are right-justified strings behind zeros (650-byte rows whose strings are ~160 bytes for Smith-Waterman
+// alignments of 150 bp reads).  Before a chunk's rows cross PCIe, the columns from the chunk's smallest readStart on (rounded
+// down to 64) are packed into dense rows of AL - col bytes -- one linear copy then carries a third of the bytes (a pitched
+// hipMemcpy2DAsync of the same window took 0.85 s per 131,072 rows on this stack: profiles/r04_d2h_rows.txt).  One block
+// per row; *min_start is the word traceback_kernel left.
+struct CompactArgs {
+    const uint8_t *rows;      // n_rows * AL
+    uint8_t *out;             // n_rows * (AL - col)
+    const int *min_start;
+    long long n_rows;
+    int AL;
+};
+
+__device__ __forceinline__ int first_copied_column(int min_start, int AL) {
+    int c = min_start < 0 ? 0 : (min_start > AL ? AL : min_start);
+    return c & ~63;
+}
+
+__global__ void __launch_bounds__(256)
+compact_rows_kernel(const CompactArgs a) {
+    const int col = first_copied_column(*a.min_start, a.AL), w = a.AL - col;
+    const uint8_t *src = a.rows + (long long)blockIdx.x * a.AL + col;
+    uint8_t *dst = a.out + (long long)blockIdx.x * w;
+    for (int k = 4 * threadIdx.x; k + 4 <= w; k += 4 * 256)
+        *reinterpret_cast<u32_any_align *>(dst + k) = *reinterpret_cast<const u32_any_align *>(src + k);
+    if ((int)threadIdx.x < (w & 3)) dst[(w & ~3) + threadIdx.x] = src[(w & ~3) + threadIdx.x];
 }
 #endif
 
