@@ -842,6 +842,10 @@ def main(argv=None):
             "vs_baseline": None, "dtype": cells, "data": "synthetic",
             "config": {"workload": workload, "pairs_per_gpu": n, "read_length": RR, "ref_length": FF,
                        "kernel_geometry": "%dx%d" % (d["group_lanes"], d["rows_per_lane"])},
+            # banded workload: `value` counts the cells of the FULL matrix (the metric of BASELINE config 5 as north_star words
+            # it); the cells the band actually holds -- what the kernel sweeps -- are far fewer: both rates, side by side
+            **({"swept_gcups": round(world * n * d.get("band_cells_per_pair", 0) / elapsed * args.steps / 1e9, 1),
+                "band_cells_per_pair": d.get("band_cells_per_pair"), "full_matrix_cells_per_pair": RR * FF} if long_mode else {}),
             "roofline": roofline_record(n, RR, FF, k_ms, kernel_name, pmc_key,
                                         {"band_waves_per_cu": d.get("band_waves_per_cu"), "band_lds_per_wave": d.get("band_lds_per_wave")} if long_mode else None),
         }

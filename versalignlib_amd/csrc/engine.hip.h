@@ -177,7 +177,7 @@ public:
         if (!env) return;
         static const char *const known[] = {"no_sym", "no_tag", "no_f16", "no_fused", "no_prof_key", "no_overlap", "no_band_chain",
                                             "force_long", "wide_align", "no_direct_out", "ragged_min", "chunk_bytes",
-                                            "align_chunk_bytes", "direct_bytes", "scratch_cap_mb", "whole_rows"};
+                                            "align_chunk_bytes", "direct_bytes", "scratch_cap_mb", "whole_rows", "short_strips"};
         std::string s(env);
         for (size_t at = 0; at <= s.size();) {
             const size_t end = std::min(s.find(',', at), s.size());
@@ -305,6 +305,7 @@ public:
     struct BandPlan {
         bool usable = false, unit_delay = false;
         int nb = 0, pad_rows = 0, d = 0, ring_depth = 0, code_cols = 0, events = 0;
+        long long cells = 0;                // DP cells one pair's band windows hold (what the chain actually sweeps)
         std::vector<BandBlock> blocks;
         std::vector<int> fill_to;
     };
@@ -628,6 +629,7 @@ private:
     BandPlan band_plan_;               // banded linear SW: the block chain's plan for band_plan_width_, its tables on the device
     int band_plan_width_ = -1;
     int band_blocks_per_cu_ = 0, band_lds_ = 0;          // of the last block-chain launch (describe)
+    int long_strip_rows_ = 0;                            // rows per strip of the last score_long_kernel launch (describe)
     BandBlock *d_band_blocks_ = nullptr;
     int *d_band_fill_ = nullptr;
     int cu_count_ = 0;

@@ -170,7 +170,7 @@ std::string Engine::describe(int opt, long long n) const {
              "\"rows_per_lane\": %d, \"padded_rows\": %d, \"pairs_per_wave\": %d, \"waves_per_block\": %d, "
              "\"lds_per_wave\": %d, \"lds_per_block\": %d, \"steps\": %d, \"blocks\": %lld, \"long_mode\": %d, "
              "\"band_width\": %d, \"ragged_batching\": %d, \"ragged_launches\": %d, \"ragged_cell_fraction\": %.4f, "
-             "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"band_block_rows\": %d, \"band_col_align\": %d, \"band_waves_per_cu\": %d, \"band_lds_per_wave\": %d, \"d2h_row_mb\": %.1f, \"full_row_mb\": %.1f, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
+             "\"score_cells\": \"%s\", \"direct_call\": %d, \"packed_classes\": %d, \"direct_out\": %d, \"band_block_rows\": %d, \"band_col_align\": %d, \"band_waves_per_cu\": %d, \"band_lds_per_wave\": %d, \"band_cells_per_pair\": %lld, \"long_strip_rows\": %d, \"d2h_row_mb\": %.1f, \"full_row_mb\": %.1f, \"host_gather_ms\": %.3f, \"host_classify_ms\": %.3f, \"host_wait_ms\": %.3f, \"host_drain_ms\": %.3f}",
              arch_.c_str(), device_, opt & 0xF, sc_.affine ? 1 : 0, plan_.geo->G, plan_.geo->K,
              plan_.geo->G * plan_.geo->K, plan_.pairs_per_wave, plan_.waves_per_block, plan_.lds.total,
              plan_.lds.total * plan_.waves_per_block, F_ + plan_.geo->G - 1, n > 0 ? (n + ppb - 1) / ppb : 0,
@@ -178,7 +178,7 @@ std::string Engine::describe(int opt, long long n) const {
              host_stats_.cells_padded > 0 ? host_stats_.cells_swept / host_stats_.cells_padded : 1.0,
              score_cell_format(opt & 0xF), host_stats_.direct, host_stats_.packed, host_stats_.direct_out,
              ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? kBandK : VALIGN_HIP_BAND_BLOCK_ROWS,
-             ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? 1 : VALIGN_HIP_BAND_COL_ALIGN, band_blocks_per_cu_, band_lds_, host_stats_.d2h_row_bytes / 1e6, host_stats_.full_row_bytes / 1e6, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
+             ((opt & 0xF) == kAlgSW && band_chain_in_use()) ? 1 : VALIGN_HIP_BAND_COL_ALIGN, band_blocks_per_cu_, band_lds_, (band_plan_width_ == band_width_ && band_plan_.usable) ? band_plan_.cells : 0ll, long_strip_rows_, host_stats_.d2h_row_bytes / 1e6, host_stats_.full_row_bytes / 1e6, host_stats_.gather_ms, host_stats_.classify_ms, host_stats_.wait_ms,
              host_stats_.drain_ms);
     return buf;
 }

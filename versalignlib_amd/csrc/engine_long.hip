@@ -4,16 +4,33 @@
 
 namespace valign {
 
-static const void *const kLongAffineKernels[2][2][2] = {       // [alg][same scores both ways][int32 cells]
-    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true, true>},
-     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true, true>}},
-    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true, true>},
-     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false, true>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, true, true>}}};
-static const void *const kLongKernels[2][2][2] = {     // [alg][gap_read == gap_ref][int32 cells]
-    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, true>},
-     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, true>}},
-    {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, true>},
-     {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false>, (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, true>}}};
+// The strip kernels of one geometry: [affine][alg][same scores both ways][int32 cells]
+struct LongGeometry {
+    int G, K;
+    int lds[2];                        // per wave: linear / affine
+    const void *kernel[2][2][2][2];
+};
+template <int G, int K>
+constexpr LongGeometry long_geometry() {
+    return LongGeometry{
+        G, K, {LongLds<G, K, false>::kTotal, LongLds<G, K, true>::kTotal},
+        {{{{(const void *)&score_long_kernel<G, K, kAlgSW, false, false>, (const void *)&score_long_kernel<G, K, kAlgSW, false, true>},
+           {(const void *)&score_long_kernel<G, K, kAlgSW, true, false>, (const void *)&score_long_kernel<G, K, kAlgSW, true, true>}},
+          {{(const void *)&score_long_kernel<G, K, kAlgNW, false, false>, (const void *)&score_long_kernel<G, K, kAlgNW, false, true>},
+           {(const void *)&score_long_kernel<G, K, kAlgNW, true, false>, (const void *)&score_long_kernel<G, K, kAlgNW, true, true>}}},
+         {{{(const void *)&score_long_kernel<G, K, kAlgSW, false, false, true>, (const void *)&score_long_kernel<G, K, kAlgSW, false, true, true>},
+           {(const void *)&score_long_kernel<G, K, kAlgSW, true, false, true>, (const void *)&score_long_kernel<G, K, kAlgSW, true, true, true>}},
+          {{(const void *)&score_long_kernel<G, K, kAlgNW, false, false, true>, (const void *)&score_long_kernel<G, K, kAlgNW, false, true, true>},
+           {(const void *)&score_long_kernel<G, K, kAlgNW, true, false, true>, (const void *)&score_long_kernel<G, K, kAlgNW, true, true, true>}}}}};
+}
+// 16 x 10: strips of 160 rows -- the blocks the strip band is defined on (include/valign_hip.h), four lane groups = eight
+// pairs per wave.  64 x 10 (round 4): strips of 640 rows for UNBANDED sweeps -- a quarter of the boundary-row traffic and
+// of the per-strip work, and ONE lane group per wave, so the LDS rings shrink from four sets to one (affine: 20.7 -> 14 KB
+// per wave, 7 -> 11 waves per CU).  These kernels are bound by how often a wave may issue, not by latency
+// (profiles/r04_band_two_chains.txt): waves per SIMD are what they lacked.
+static const LongGeometry kLongStrips = long_geometry<kLongG, kLongK>();
+static const LongGeometry kLongTall = long_geometry<64, 8>();
+static_assert(kLongG * kLongK == VALIGN_HIP_BAND_BLOCK_ROWS, "banded strips are the API's blocks");
 
 Engine::BandPlan Engine::make_band_plan() const {
     BandPlan p;
@@ -69,6 +86,8 @@ Engine::BandPlan Engine::make_band_plan() const {
         if (lo[(size_t)b] <= hi[(size_t)b]) {
             k.lo = lo[(size_t)b];
             k.span = hi[(size_t)b] - lo[(size_t)b];
+            const int r_lo = std::max(b * K - p.pad_rows, 0), r_hi = std::min((b + 1) * K - p.pad_rows - 1, R - 1);
+            p.cells += (long long)(k.span + 1) * (r_hi - r_lo + 1);
         }
         // (blocks of padding write zeros whatever they are asked: their successor may read any slot)
         k.delay = b > first_real ? p.d - (start[(size_t)b] - start[(size_t)b - 1]) : 2;
@@ -163,13 +182,16 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
         throw std::runtime_error("band_width applies to Smith-Waterman scores only");
     // linear gaps, banded: the cyclic block chain (int32 cells whatever score_width says: same results in the int16 range)
     if (band_width_ > 0 && alg == kAlgSW && score_band_device(n, d_reads, d_refs, d_scores, stream)) return;
-    const int rows = kLongG * kLongK;
-    const int ppw = 2 * (kWave / kLongG);
+    // unbanded sweeps of reads beyond a few strips take the tall strips; a band is defined on the 160-row blocks
+    const LongGeometry &geo = (band_width_ == 0 && R_ > 2 * kLongTall.G * kLongTall.K && !dbg_.on("short_strips")) ? kLongTall : kLongStrips;
+    const int rows = geo.G * geo.K;
+    const int ppw = 2 * (kWave / geo.G);
+    long_strip_rows_ = rows;
     LongArgs a;
     a.R = R_;
     a.F = F_;
     a.strips = std::max(1, (R_ + rows - 1) / rows);
-    a.row_dwords = ((F_ + kLongG + kPhase - 1) / kPhase) * kPhase + kPhase;
+    a.row_dwords = ((F_ + geo.G + kPhase - 1) / kPhase) * kPhase + kPhase;
     a.band_half = (band_width_ > 0 && alg == kAlgSW) ? band_width_ / 2 : -1;
     a.match = (short)sc_.match;
     a.mismatch = (short)sc_.mismatch;
@@ -192,9 +214,9 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
         hip_check(hipMalloc((void **)&d_brow_, brow_bytes_), "hipMalloc(boundary rows)");
     }
     const bool affine_sym = sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
-    const void *fn = sc_.affine ? kLongAffineKernels[alg][affine_sym ? 1 : 0][wide ? 1 : 0]
-                                : kLongKernels[alg][(sc_.gap_read == sc_.gap_ref && !no_sym_) ? 1 : 0][wide ? 1 : 0];
-    const int long_lds = sc_.affine ? LongLds<kLongG, kLongK, true>::kTotal : LongLds<kLongG, kLongK, false>::kTotal;
+    const bool sym = sc_.affine ? affine_sym : (sc_.gap_read == sc_.gap_ref && !no_sym_);
+    const void *fn = geo.kernel[sc_.affine ? 1 : 0][alg][sym ? 1 : 0][wide ? 1 : 0];
+    const int long_lds = geo.lds[sc_.affine ? 1 : 0];
     for (long long begin = 0; begin < n; begin += chunk) {
         const long long cnt = std::min(chunk, n - begin);
         a.reads = d_reads + (size_t)begin * R_;

@@ -79,8 +79,11 @@ struct Cell<true> {
 template <int G, int K, bool AFFINE = false>
 struct LongLds {
     using geo = Geo<G, K>;
-    static constexpr int kCodes = geo::kProfBytes;                        // [groups][kRing][2] bytes
-    static constexpr int kIn = kCodes + geo::kGroups * kRing * 2;         // [groups][kRing] dwords
+    // The ring of reference slab numbers is read across the whole lane skew: lane G - 1 is G - 1 columns behind lane 0,
+    // the sweep looks two columns ahead and the refill runs a phase + kLead ahead -- 64 lanes need 256 slots
+    static constexpr int kCodeRing = (G - 1) + 2 + kPhase + kLead <= kRing ? kRing : 2 * kRing;
+    static constexpr int kCodes = geo::kProfBytes;                        // [groups][kCodeRing][2] bytes
+    static constexpr int kIn = kCodes + geo::kGroups * kCodeRing * 2;         // [groups][kRing] dwords
     static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
     static constexpr int kInF = kOut + geo::kGroups * kRing * 4;          // affine: the F values of the boundary rows, same rings
     static constexpr int kOutF = kInF + geo::kGroups * kRing * 4;
@@ -91,7 +94,8 @@ struct LongLds {
 template <int G, int K>
 __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows, int band_half, int &c_lo, int &c_hi) {
     constexpr int rows = G * K;
-    static_assert(rows == VALIGN_HIP_BAND_BLOCK_ROWS, "the band is defined on blocks of this many rows (include/valign_hip.h)");
+    // (a band is only ever swept with the geometry whose strips are the API's blocks: Engine::score_long_device checks
+    // G * K == VALIGN_HIP_BAND_BLOCK_ROWS there; taller strips exist for unbanded sweeps)
     static_assert(VALIGN_HIP_BAND_COL_ALIGN == 4, "c_lo is rounded down to a multiple of 4 below");
     if (band_half < 0 || R <= 0) {
         c_lo = 0;
@@ -109,8 +113,9 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
 // AFFINE: Gotoh recurrence (E along the row in registers like H; F down the column -- through the lanes by DPP
 // and from strip to strip through a second boundary row next to H's).  SYM then means open_read == open_ref and
 // ext_read == ext_ref: H - open is computed once per cell.
+// (G == 64: LDS lets eleven one-wave blocks share a CU -- ask the compiler for a register budget that lets three waves share a SIMD)
 template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, G == 64 ? 3 : 1)
 score_long_kernel(const LongArgs args) {
     using geo = Geo<G, K>;
     using lay = LongLds<G, K, AFFINE>;
@@ -134,7 +139,7 @@ score_long_kernel(const LongArgs args) {
     unsigned *ring_out_f = reinterpret_cast<unsigned *>(valign_smem + lay::kOutF);
 
     const unsigned lane_base = lds_offset(prof) + l * geo::kLaneBytes;
-    const unsigned codes_base = lds_offset(codes) + grp * (kRing * 2);
+    const unsigned codes_base = lds_offset(codes) + grp * (lay::kCodeRing * 2);
     const unsigned in_base = lds_offset(ring_in) + grp * (kRing * 4);
     const unsigned in_base_f = lds_offset(ring_in_f) + grp * (kRing * 4);
     unsigned *out_grp = ring_out + grp * kRing;
@@ -161,7 +166,7 @@ score_long_kernel(const LongArgs args) {
     for (int i = lane; i < geo::kPairStride / 4; i += kWave)
         reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[i] = 0u;
     // the sweep prefetches profile rows through whatever slab numbers the ring holds: start with valid ones
-    for (int i = lane; i < geo::kGroups * kRing * 2; i += kWave) codes[i] = (unsigned char)geo::kZeroSlab;
+    for (int i = lane; i < geo::kGroups * lay::kCodeRing * 2; i += kWave) codes[i] = (unsigned char)geo::kZeroSlab;
 
     for (int s = 0; s < args.strips; ++s) {
         // ---- query profile of this strip's rows ----
@@ -247,7 +252,7 @@ score_long_kernel(const LongArgs args) {
                 lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
             }
             {
-                const unsigned next_addr = codes_base + (((j + 2) & (kRing - 1)) << 1);
+                const unsigned next_addr = codes_base + (((j + 2) & (lay::kCodeRing - 1)) << 1);
                 ca_next = *(lds_cu8 *)(next_addr);
                 cb_next = *(lds_cu8 *)(next_addr + 1);
             }
@@ -371,13 +376,16 @@ score_long_kernel(const LongArgs args) {
         u32x4 pre_brow = {0u, 0u, 0u, 0u}, pre_frow = {0u, 0u, 0u, 0u};
         bool pre_brow_valid = false;
         auto prefetch = [&](int t0) __attribute__((always_inline)) {
+            // (lanes beyond the wave's pairs / groups have nothing to fetch: G = 64 has one group of two pairs)
             const int p = lane / 8, c0 = c_lo + kLead + t0 + (lane % 8) * 8;  // lane -> pair lane/8, eight columns
             const int ps = p > last ? last : p;
             const uint8_t *src = args.refs + (pair0 + ps) * F;
+            if (p < geo::kPairs) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x) pre_base[x] = (c0 + x < F) ? src[c0 + x] : (unsigned char)0;
+                for (int x = 0; x < 8; ++x) pre_base[x] = (c0 + x < F) ? src[c0 + x] : (unsigned char)0;
+            }
             const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;   // lane -> group lane/16, four columns
-            pre_brow_valid = s > 0 && col + 4 <= args.row_dwords;
+            pre_brow_valid = g < geo::kGroups && s > 0 && col + 4 <= args.row_dwords;
             if (pre_brow_valid) {       // L2-served load: the same addresses were read two strips ago and rewritten since
                 pre_brow = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4 *>(brow_prev + brow_slot_of(g, half, 0) * args.row_dwords + col));
@@ -389,15 +397,18 @@ score_long_kernel(const LongArgs args) {
         auto commit = [&](int t0) __attribute__((always_inline)) {
             {
                 const int p = lane / 8, c0 = c_lo + kLead + t0 + (lane % 8) * 8;
-                unsigned char *dst = codes + (p / 2) * (kRing * 2) + (p & 1);
+                unsigned char *dst = codes + (p / 2) * (lay::kCodeRing * 2) + (p & 1);
+                if (p < geo::kPairs) {
 #pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const int col = c0 + x;
-                    const int c = col < F ? base_class(pre_base[x]) : 0;
-                    dst[(col & (kRing - 1)) * 2] =
-                        (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+                    for (int x = 0; x < 8; ++x) {
+                        const int col = c0 + x;
+                        const int c = col < F ? base_class(pre_base[x]) : 0;
+                        dst[(col & (lay::kCodeRing - 1)) * 2] =
+                            (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+                    }
                 }
                 const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;
+                if (g >= geo::kGroups) return;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (pre_brow_valid) {
                     v.x = (col + 0 >= p_lo && col + 0 <= p_hi) ? pre_brow.x : 0u;      // outside the previous strip's
@@ -431,9 +442,11 @@ score_long_kernel(const LongArgs args) {
         {
             const int p = lane / 8, col = c_lo + (lane % 8);
             const int ps = p > last ? last : p;
-            const int c = col < F ? base_class(args.refs[(pair0 + ps) * F + col]) : 0;
-            codes[(p / 2) * (kRing * 2) + (p & 1) + (col & (kRing - 1)) * 2] =
-                (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+            if (p < geo::kPairs) {
+                const int c = col < F ? base_class(args.refs[(pair0 + ps) * F + col]) : 0;
+                codes[(p / 2) * (lay::kCodeRing * 2) + (p & 1) + (col & (lay::kCodeRing - 1)) * 2] =
+                    (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
+            }
             if (lane < geo::kGroups * kLead) {
                 const int g = lane / kLead, bc = c_lo + (lane % kLead);
                 unsigned v = 0u, vf = border_f_bits;
@@ -450,7 +463,7 @@ score_long_kernel(const LongArgs args) {
             commit(t0);
             if (t0 == 0) {
                 __syncthreads();
-                const unsigned a0 = codes_base + ((j & (kRing - 1)) << 1), a1 = codes_base + (((j + 1) & (kRing - 1)) << 1);
+                const unsigned a0 = codes_base + ((j & (lay::kCodeRing - 1)) << 1), a1 = codes_base + (((j + 1) & (lay::kCodeRing - 1)) << 1);
                 const unsigned ca = *(lds_cu8 *)(a0), cb = *(lds_cu8 *)(a0 + 1);
                 if constexpr (WIDE) {
                     lds_load_lane<K>(lane_base + (half ? cb : ca) * geo::kPairStride, pa);
@@ -485,7 +498,7 @@ score_long_kernel(const LongArgs args) {
             const int g = lane / 16;
             for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
                 const int oc = c_lo + ph * kPhase + (lane % 16) * 4;
-                if (oc + 4 <= args.row_dwords) {
+                if (g < geo::kGroups && oc + 4 <= args.row_dwords) {
                     *reinterpret_cast<uint4 *>(brow_cur + brow_slot_of(g, half, 0) * args.row_dwords + oc) =
                         *reinterpret_cast<const uint4 *>(ring_out + g * kRing + (oc & (kRing - 1)));
                     if constexpr (AFFINE)
