@@ -107,3 +107,27 @@ def test_block_chain_on_a_large_batch():
     got = eng.score_device(0, d_reads, d_refs).cpu().numpy()
     eng.close()
     assert np.array_equal(got, np.tile(exp, 65)[:4099])
+
+
+@pytest.mark.parametrize("R,F,n,band,seed", [(1000, 1000, 37, 64, 61), (1000, 1300, 33, 16, 62), (1300, 1000, 30, 32, 63),
+                                             (700, 2100, 18, 128, 64), (100, 120, 50, 8, 65), (2049, 2000, 9, 512, 66),
+                                             (10000, 10000, 4, 512, 67)])
+def test_affine_block_chain_matches_the_block_band(R, F, n, band, seed):
+    """Round 4: affine gaps on the chain too (E in registers, F handed from lane to lane beside H): symmetric scores (H - open
+    shared by E and F) and four different ones, unit-delay (DPP) and ring shapes -- against the oracle's banded Gotoh
+    recurrence on the chain's own blocks (16 rows, column alignment 1), between the per-cell band and the full matrix."""
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, sub_rate=0.1, indel_rate=0.02 if R <= 4000 else 0.001, n_run_frac=0.1,
+                                   short_frac=0.15, lowercase_frac=0.05, junk_frac=0.05)
+    for aff in ((-5, -1, -5, -1), (-4, -2, -6, -1)):
+        sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
+        eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
+        eng.set_band_width(band)
+        d = eng.describe(0, n)
+        assert (d["band_block_rows"], d["band_col_align"], d["score_cells"]) == (16, 1, "int32"), d
+        got = eng.score_host(0, reads, refs, threads=4)
+        eng.close()
+        exp = cpu_ref.score_banded_sw(reads, refs, band, sc, threads=8, block_rows=16, col_align=1, affine=True)
+        assert np.array_equal(got, exp), (aff, np.nonzero(got != exp)[0][:8], got[:8], exp[:8])
+        assert (cpu_ref.score_banded_sw(reads, refs, band, sc, threads=8, affine=True) <= got).all()
+        if R <= 2100:
+            assert (got <= cpu_ref.score(0, reads, refs, sc, threads=8, affine=True, wide=True)).all()

@@ -262,7 +262,8 @@ def test_config5_shape_affine_and_banded_affine():
     aff = (-5, -1, -5, -1)
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
     keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
-    block_rows, col_align = band_constants()
+    block_rows, col_align = band_constants(R, F, 512, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
+    assert (block_rows, col_align) == (16, 1)            # the affine block chain (round 4)
     with host.Plugin(build.HIP_PLUGIN, R, F, **keys) as hip:
         assert np.array_equal(hip.score_alignments(0, reads, refs), cpu_ref.score(0, reads, refs, sc, threads=8, affine=True, wide=True))
         assert '"score_cells": "int16"' in hip.drain_log()
@@ -283,7 +284,9 @@ def test_banded_affine(band):
     aff = (-6, -2, -4, -1)
     sc = cpu_ref.Scoring.make(2, -1, -3, -3, *aff)
     keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
-    block_rows, col_align = band_constants()
+    # (the blocks of the band the library computes for THIS shape and scoring, as it reports them: since round 4 affine
+    # bands run on the block chain too -- 16 rows, column alignment 1 -- wherever the chain's plan fits)
+    block_rows, col_align = band_constants(R, F, band, hipkernel.Scoring.make(2, -1, -3, -3, *aff))
     with host.Plugin(build.HIP_PLUGIN, R, F, band_width=band, **keys) as hip:
         got = hip.score_alignments(0, reads, refs)
     assert np.array_equal(got, cpu_ref.score_banded_sw(reads, refs, band, sc, threads=8, block_rows=block_rows, col_align=col_align, affine=True))

@@ -61,6 +61,7 @@ struct BandArgs {
     int code_cols;              // reference ring columns per group (power of two)
     short match, mismatch;
     short gap_read, gap_ref;
+    short open_read, ext_read, open_ref, ext_ref;     // AFFINE instantiations (all <= 0)
 };
 
 template <int K>
@@ -76,8 +77,10 @@ struct BandLds {
         const int at = codes(code_cols) + kBandGroups * code_cols, a = ring_depth * 4;
         return (at + a - 1) / a * a;
     }
-    // (ring_depth 0: the unit-delay kernel, no ring)
-    __host__ __device__ static int total(int code_cols, int ring_depth) { return ring(code_cols, ring_depth ? ring_depth : 1) + kWave * ring_depth * 4; }
+    // (ring_depth 0: the unit-delay kernel, no ring; affine: a second ring, for F, behind the first)
+    __host__ __device__ static int total(int code_cols, int ring_depth, bool affine = false) {
+        return ring(code_cols, ring_depth ? ring_depth : 1) + kWave * ring_depth * 4 * (affine ? 2 : 1);
+    }
 };
 
 // SYM: gap_read == gap_ref (one saturating subtract per cell serves both neighbours).
@@ -85,7 +88,12 @@ struct BandLds {
 // per block, BASELINE config 5's 10 kbp x 10 kbp at 512 diagonals is such a case) -- then the cell travels by DPP
 // (lane 0 <- lane 31, lane 32 <- lane 63 through two scalar registers) and no LDS round trip sits between two steps of the
 // chain.  Otherwise the delay ring, whose reads run one step ahead (the host plans every delay >= 2 for that).
-template <int K, bool SYM, bool UNIT>
+// AFFINE (round 4): Gotoh's recurrence on the same chain -- E lives in registers like H (one value per row, carried along
+// the row), F runs down the column: through the lane's rows in registers and from lane to lane beside H (a second DPP
+// move / a second delay ring).  All values floored at 0 by the saturating subtracts, which for Smith-Waterman is the
+// recurrence itself (a gap score below zero never beats the floor).  SYM then means open_read == open_ref and ext_read ==
+// ext_ref: H - open is computed once per cell and serves E of the next column and F of the next row.
+template <int K, bool SYM, bool UNIT, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 score_band_kernel(const BandArgs args) {
     static_assert(K % 8 == 0, "rows per lane come in chunks of eight int16 scores");
@@ -110,6 +118,9 @@ score_band_kernel(const BandArgs args) {
     constexpr unsigned kSlabStride = kBandG * 16;
     constexpr unsigned zero_slab = 4 * kBandGroups;                   // (class * kBandGroups + grp for a real class)
     const unsigned gmag_ref = (unsigned)(-(int)args.gap_ref), gmag_read = (unsigned)(-(int)args.gap_read);
+    const unsigned omag_read = (unsigned)(-(int)args.open_read), emag_read = (unsigned)(-(int)args.ext_read);
+    const unsigned omag_ref = (unsigned)(-(int)args.open_ref), emag_ref = (unsigned)(-(int)args.ext_ref);
+    const unsigned ring_f = (unsigned)kWave * (unsigned)args.ring_depth * 4u;       // the F ring sits behind the H ring
 
     // the all-zero slabs and the never-filled part of the reference ring, once
     for (int i = lane; i < lay::kRowChunks * kBandG * 4; i += kWave) {
@@ -131,13 +142,18 @@ score_band_kernel(const BandArgs args) {
 
     for (int i = lane; i < kBandGroups * args.code_cols; i += kWave) codes[i] = (unsigned char)zero_slab;
     if (!UNIT)
-        for (int i = lane; i < kWave * args.ring_depth; i += kWave)
+        for (int i = lane; i < kWave * args.ring_depth * (AFFINE ? 2 : 1); i += kWave)
             reinterpret_cast<unsigned *>(valign_smem + lay::ring(args.code_cols, args.ring_depth))[i] = 0u;
 
-    int Hl[K], Gl[K];
+    // per row: H of the previous column; linear gaps: max(H - g, 0) beside it (shared-gap form); affine: E of the previous
+    // column and, with symmetric scores, max(H - open, 0)
+    int Hl[K], Gl[K], El[AFFINE ? K : 1];
 #pragma unroll
     for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+#pragma unroll
+    for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = 0;
     int up0 = 0, up_in = 0, best = 0;      // up_in: the predecessor's cell for the coming step (read one step ahead)
+    int fup_in = 0;                        // affine: the predecessor's F beside it
     // u: the lane's column minus the first column of its window (inside the window while 0 <= u <= span);
     // ca: LDS address of the ring entry two columns ahead of the lane's
     int u = -0x20000000, span = 0;
@@ -216,7 +232,11 @@ score_band_kernel(const BandArgs args) {
     auto step = [&](unsigned (&S)[K / 2], unsigned (&Snext)[K / 2]) __attribute__((always_inline)) {
         const int diag0 = up0;
         up0 = up_in;                                                     // the cell above this block's first row
-        if (!UNIT) up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));      // ... of the next step (written >= 1 step ago)
+        const int fup0 = fup_in;                                         // (affine) ... and its F
+        if (!UNIT) {
+            up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));   // ... of the next step (written >= 1 step ago)
+            if (AFFINE) fup_in = (int)*(lds_cu32 *)(pred_ring + ring_f + (rd4 & ring_mask));
+        }
         load_scores(addr_next, Snext);                                   // step t + 1
         // (inline assembly: through the compiler the byte comes back as an "any-extended" load and is masked again every
         // step; ds_read_u8 zero-extends.  The compiler does not count this load -- LDS returns in order, its own waits only
@@ -224,8 +244,41 @@ score_band_kernel(const BandArgs args) {
         unsigned code;
         asm volatile("ds_read_u8 %0, %1" : "=v"(code) : "v"(ca));        // step t + 2
         ca = ((ca + 1u) & code_mask) | codes_lds;
-        int h_out = 0;
-        if ((unsigned)u <= (unsigned)span) {
+        int h_out = 0, f_out = 0;
+        if (AFFINE) {
+            if ((unsigned)u <= (unsigned)span) {
+                int f = fup0;
+                int ho = (int)__builtin_elementwise_sub_sat((unsigned)up0, omag_ref);          // H - open of the row above
+                int d_cur = diag0 + score_of(S, 0), d_prev = 0, h = 0;
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    int d_next = 0;
+                    if (q + 1 < K) d_next = Hl[q] + score_of(S, q + 1);  // before Hl[q] is overwritten
+                    const int ex = (int)__builtin_elementwise_sub_sat((unsigned)El[q], emag_read);
+                    const int eo = SYM ? Gl[q] : (int)__builtin_elementwise_sub_sat((unsigned)Hl[q], omag_read);
+                    const int e = ex > eo ? ex : eo;
+                    const int fx = (int)__builtin_elementwise_sub_sat((unsigned)f, emag_ref);
+                    f = fx > ho ? fx : ho;
+                    int m = d_cur > e ? d_cur : e;
+                    m = m > f ? m : f;
+                    h = m;
+                    El[q] = e;
+                    Hl[q] = m;
+                    ho = (int)__builtin_elementwise_sub_sat((unsigned)m, omag_ref);
+                    if (SYM) Gl[q] = ho;
+                    if (q & 1) {
+                        int b2 = best > d_prev ? best : d_prev;
+                        best = b2 > d_cur ? b2 : d_cur;
+                    } else if (q == K - 1) {
+                        best = best > d_cur ? best : d_cur;
+                    }
+                    d_prev = d_cur;
+                    d_cur = d_next;
+                }
+                h_out = h;
+                f_out = f;
+            }
+        } else if ((unsigned)u <= (unsigned)span) {
             int h = up0;
             int up_c = (int)__builtin_elementwise_sub_sat((unsigned)up0, gmag_ref);
             int d_cur = diag0 + score_of(S, 0), d_prev = 0;
@@ -259,8 +312,15 @@ score_band_kernel(const BandArgs args) {
             int v = __builtin_amdgcn_update_dpp(h_out, h_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
             asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32" : "+v"(v) : "s"(s31), "s"(s63));
             up_in = v;
+            if (AFFINE) {
+                const int f31 = __builtin_amdgcn_readlane(f_out, 31), f63 = __builtin_amdgcn_readlane(f_out, 63);
+                int vf = __builtin_amdgcn_update_dpp(f_out, f_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+                asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32" : "+v"(vf) : "s"(f31), "s"(f63));
+                fup_in = vf;
+            }
         } else {
             *(__attribute__((address_space(3))) unsigned *)(my_ring + (t4 & ring_mask)) = (unsigned)h_out;
+            if (AFFINE) *(__attribute__((address_space(3))) unsigned *)(my_ring + ring_f + (t4 & ring_mask)) = (unsigned)f_out;
             rd4 += 256;
             t4 += 256;
         }
@@ -281,6 +341,8 @@ score_band_kernel(const BandArgs args) {
         if (l == ls) {
 #pragma unroll
             for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+#pragma unroll
+            for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = 0;
             up0 = 0;
             u = blk.start - blk.lo;             // (an empty block: lo = 0x3FFFFFFF -- never inside)
             span = blk.span;
@@ -289,6 +351,7 @@ score_band_kernel(const BandArgs args) {
             if (!UNIT) {
                 // this step's cell from above now, the read for the next step follows in the step itself
                 up_in = (int)*(lds_cu32 *)(pred_ring + ((t4 - 256u * (unsigned)blk.delay) & ring_mask));
+                if (AFFINE) fup_in = (int)*(lds_cu32 *)(pred_ring + ring_f + ((t4 - 256u * (unsigned)blk.delay) & ring_mask));
                 rd4 = t4 + 256u - 256u * (unsigned)blk.delay;
             }
         }

@@ -113,13 +113,13 @@ Engine::BandPlan Engine::make_band_plan() const {
     // Limits of the kernel: ring addressing (base | offset) and one CU's LDS.
     if (p.code_cols > 2048 || p.ring_depth > 64) return p;
     if (p.unit_delay) p.ring_depth = 0;
-    if (BandLds<kBandK>::total(p.code_cols, p.ring_depth) > 40 * 1024) return p;
+    if (BandLds<kBandK>::total(p.code_cols, p.ring_depth, sc_.affine) > 40 * 1024) return p;
     p.usable = true;
     return p;
 }
 
 bool Engine::score_band_device(long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores, hipStream_t stream) {
-    if (no_band_chain_ || sc_.affine || band_width_ <= 0) return false;
+    if (no_band_chain_ || band_width_ <= 0) return false;
     if (band_plan_width_ != band_width_) {
         band_plan_ = make_band_plan();
         band_plan_width_ = band_width_;
@@ -155,10 +155,18 @@ bool Engine::score_band_device(long long n, const uint8_t *d_reads, const uint8_
     a.mismatch = (short)sc_.mismatch;
     a.gap_read = (short)sc_.gap_read;
     a.gap_ref = (short)sc_.gap_ref;
-    const bool sym = sc_.gap_read == sc_.gap_ref && !no_sym_;
-    const void *fn = p.unit_delay ? (sym ? (const void *)&score_band_kernel<kBandK, true, true> : (const void *)&score_band_kernel<kBandK, false, true>)
-                                  : (sym ? (const void *)&score_band_kernel<kBandK, true, false> : (const void *)&score_band_kernel<kBandK, false, false>);
-    const int lds = BandLds<kBandK>::total(p.code_cols, p.ring_depth);
+    a.open_read = (short)sc_.open_read;
+    a.ext_read = (short)sc_.ext_read;
+    a.open_ref = (short)sc_.open_ref;
+    a.ext_ref = (short)sc_.ext_ref;
+    const bool sym = (sc_.affine ? (sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref) : sc_.gap_read == sc_.gap_ref) && !no_sym_;
+    static const void *const kernels[2][2][2] = {        // [affine][one score both ways][unit delay]
+        {{(const void *)&score_band_kernel<kBandK, false, false>, (const void *)&score_band_kernel<kBandK, false, true>},
+         {(const void *)&score_band_kernel<kBandK, true, false>, (const void *)&score_band_kernel<kBandK, true, true>}},
+        {{(const void *)&score_band_kernel<kBandK, false, false, true>, (const void *)&score_band_kernel<kBandK, false, true, true>},
+         {(const void *)&score_band_kernel<kBandK, true, false, true>, (const void *)&score_band_kernel<kBandK, true, true, true>}}};
+    const void *fn = kernels[sc_.affine ? 1 : 0][sym ? 1 : 0][p.unit_delay ? 1 : 0];
+    const int lds = BandLds<kBandK>::total(p.code_cols, p.ring_depth, sc_.affine);
     // as many one-wave blocks as run side by side; each takes quads of pairs in turn (band_kernels.hip.h)
     int per_cu = 0;
     hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, (size_t)lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
@@ -173,7 +181,7 @@ bool Engine::score_band_device(long long n, const uint8_t *d_reads, const uint8_
 }
 
 bool Engine::band_chain_in_use() const {
-    return !no_band_chain_ && !sc_.affine && band_width_ > 0 && (band_plan_width_ == band_width_ ? band_plan_.usable : make_band_plan().usable);
+    return !no_band_chain_ && band_width_ > 0 && (band_plan_width_ == band_width_ ? band_plan_.usable : make_band_plan().usable);
 }
 
 void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
