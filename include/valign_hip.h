@@ -99,6 +99,11 @@ typedef struct {
 
 int valign_hip_device_count(void);
 
+/* Plugin key hip_devices = N: shard d (0-based) of a call of n pairs is the contiguous range [*begin, *begin + *count)
+ * -- ceil(n / N) pairs per shard, the last one short, trailing shards empty.  Pure arithmetic (no device needed): the one
+ * rule the shard threads and the in-plugin all-gather's buffer offsets both use.  Returns 1 on bad arguments.            */
+int valign_hip_shard_range(int n, int shards, int d, int *begin, int *count);
+
 /* One engine = one device + fixed (read_length, ref_length, scoring), like one spawned
  * kernel object.  force_group_lanes / force_rows_per_lane = 0 lets the engine choose. */
 int valign_hip_engine_create(int device, int read_length, int ref_length,
@@ -113,16 +118,27 @@ int valign_hip_set_traceback_policy(valign_hip_engine *e, int policy);
 
 /* Banded Smith-Waterman scores (an extension: the reference has no banding).  Definition, w = diagonals / 2:
  * the per-cell band is |j - floor(i * ref_length / read_length)| <= w (i, j 0-based read / ref positions).
- * The library computes AT LEAST that band: the read's rows are taken in blocks of
- * VALIGN_HIP_BAND_BLOCK_ROWS consecutive rows (the last block ends with the last row), and a block computes
- * the columns [floor(r_first * F / R) - w, floor(r_last * F / R) + w] of its rows r_first..r_last, the lower
- * end rounded down to a multiple of VALIGN_HIP_BAND_COL_ALIGN; every other cell counts as 0 and cannot hold
- * the maximum.  Hence  score(per-cell band w) <= result <= score(all cells),  and the result equals this
- * block definition exactly (oracle/cpu_ref.c, vref_score_banded_sw, restates it with the two constants as
- * parameters; block 1 / align 1 is the per-cell band).  0 (default) computes every cell; a band wider than
- * the matrix gives the unbanded result.                                                                   */
+ * The library computes AT LEAST that band: the read's rows are taken in blocks of B consecutive rows (the last
+ * block ends with the last row), and a block computes the columns [floor(r_first * F / R) - w,
+ * floor(r_last * F / R) + w] of its rows r_first..r_last, the lower end rounded down to a multiple of A; every
+ * other cell counts as 0 and cannot hold the maximum.  Hence  score(per-cell band w) <= result <= score(all
+ * cells),  and the result equals this block definition exactly (oracle/cpu_ref.c, vref_score_banded_sw[_affine],
+ * restates it with B and A as parameters; B = 1 / A = 1 is the per-cell band).
+ *
+ * WHICH (B, A) applies depends on the schedule the engine can use for (shape, band, scoring), and
+ * valign_hip_describe is the authority -- "band_block_rows" / "band_col_align" of the engine after
+ * valign_hip_set_band_width:
+ *   B = 16,  A = 1   the cyclic block chain (band_kernels.hip.h): linear gaps since round 3, affine gaps since round 4,
+ *                    wherever its plan fits (windows up to 2048 columns of reference ring, delays up to 64 steps);
+ *                    exported below as VALIGN_HIP_BAND_CHAIN_BLOCK_ROWS / VALIGN_HIP_BAND_CHAIN_COL_ALIGN;
+ *   B = 160, A = 4   row strips (long_kernels.hip.h): every other banded case; VALIGN_HIP_BAND_BLOCK_ROWS /
+ *                    VALIGN_HIP_BAND_COL_ALIGN.
+ * The chain's band is the tighter superset of the per-cell band.  0 (default) computes every cell; a band wider
+ * than the matrix gives the unbanded result.                                                                   */
 #define VALIGN_HIP_BAND_BLOCK_ROWS 160
 #define VALIGN_HIP_BAND_COL_ALIGN 4
+#define VALIGN_HIP_BAND_CHAIN_BLOCK_ROWS 16
+#define VALIGN_HIP_BAND_CHAIN_COL_ALIGN 1
 int valign_hip_set_band_width(valign_hip_engine *e, int diagonals);
 
 /* Cap (MiB) of the internal pointer scratch compute_alignments keeps in device memory (2 bits per cell and pair,

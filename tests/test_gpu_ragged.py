@@ -161,6 +161,30 @@ def test_ragged_device_resident_batch(small_bins, alg, R, F, n):
     eng.close()
 
 
+def test_ragged_device_calls_on_two_streams_share_one_context_safely(small_bins):
+    """One engine, two streams, back-to-back length-sorted device calls on different batches: the engine has ONE context
+    (pinned histogram and tables, counters, packed buffers) for device-resident calls -- a call on another stream than the
+    last one must first wait until that one is through with it, or it would rewrite the tables under its kernels."""
+    import torch
+    R, F, n = 150, 500, 40000
+    batches = []
+    for seed in (71, 72, 73, 74):
+        reads, refs = synth.make_ragged_pairs(n, R, F, seed=seed, n_run_frac=0.03, short_frac=0.02)
+        batches.append((torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda(), cpu_ref.score(host.SW, reads, refs, threads=8)))
+    eng = hipkernel.Engine(R, F)
+    eng.set_ragged_batching(2)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = []
+    for k, (d_reads, d_refs, _) in enumerate(batches):             # alternating streams, nothing waited for in between
+        outs.append(eng.score_device(host.SW, d_reads, d_refs, stream=streams[k & 1]))
+    torch.cuda.synchronize()
+    for k, (_, _, exp) in enumerate(batches):
+        got = outs[k].cpu().numpy()
+        assert np.array_equal(got, exp), (k, np.nonzero(got != exp)[0][:8])
+    eng.close()
+
+
 @pytest.mark.parametrize("packing", [1, 0])
 def test_ragged_chunks_of_the_pipeline(small_bins, monkeypatch, packing):
     """Several chunks in flight: every chunk is classified while the host gathers the next one and swept one iteration

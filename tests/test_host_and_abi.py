@@ -112,6 +112,30 @@ def test_shard_ranges():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
 
 
+def test_in_plugin_shard_split_is_one_rule_and_the_ranks_rule():
+    """hip_devices = N inside ONE process: the shard threads and the in-plugin all-gather's buffer offsets use one helper
+    (ShardSplit, hip_plugin.hip), exported as valign_hip_shard_range -- pure arithmetic, callable without a device.  It must
+    tile [0, n) without gaps or overlaps and agree with the rule the process-per-GPU ranks use (shard.shard_range)."""
+    import ctypes
+    L = ctypes.CDLL(build.HIP_PLUGIN)
+    L.valign_hip_shard_range.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)] * 2
+    for n in (0, 1, 7, 8, 9, 1000, 1001, 1 << 20, (1 << 20) + 5):
+        for shards in (1, 2, 3, 4, 8, 64):
+            at = 0
+            for d in range(shards):
+                b, c = ctypes.c_int(-1), ctypes.c_int(-1)
+                assert L.valign_hip_shard_range(n, shards, d, ctypes.byref(b), ctypes.byref(c)) == 0
+                lo, hi = shard.shard_range(n, d, shards)
+                assert c.value == hi - lo and (c.value == 0 or b.value == lo), (n, shards, d, b.value, c.value, lo, hi)
+                if c.value:
+                    assert b.value == at
+                    at += c.value
+            assert at == n
+    b, c = ctypes.c_int(), ctypes.c_int()
+    assert L.valign_hip_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) == 1
+    assert L.valign_hip_shard_range(10, 2, 2, ctypes.byref(b), ctypes.byref(c)) == 1
+
+
 def test_constructor_refuses_what_the_kernels_cannot_compute():
     """Parameter validation happens before any device is touched, so it is checkable anywhere:
     positive gap scores (the row padding needs non-positive ones) and shapes beyond the ABI's

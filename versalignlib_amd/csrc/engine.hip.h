@@ -300,7 +300,7 @@ public:
     void launch_unpack(const uint8_t *d_packed, uint8_t *d_out, long long n, int len, hipStream_t stream);
 
     // ---- banded Smith-Waterman scores, linear gaps: the cyclic block chain of band_kernels.hip.h ----
-    static constexpr int kBandK = 16;              // rows per block = the band definition's block (describe: band_block_rows)
+    static constexpr int kBandK = VALIGN_HIP_BAND_CHAIN_BLOCK_ROWS;              // rows per block = the band definition's block (describe: band_block_rows)
 
     struct BandPlan {
         bool usable = false, unit_delay = false;
@@ -592,6 +592,8 @@ private:
     std::vector<unsigned short> ref_class_;
     std::map<std::pair<int, int>, LaunchPlan> class_plans_;
     RaggedCtx rag_[kSlots + 1];                                  // one per pipeline slot, the last for device-resident batches
+    hipStream_t ragged_dev_stream_ = nullptr;                    // stream and end of the last device-resident length-sorted call
+    hipEvent_t ragged_dev_done_ = nullptr;
     uint8_t *d_read_class_ = nullptr;
     uint16_t *d_ref_class_ = nullptr;
     HostPacker packer_{R_, F_};                               // (declared after R_ / F_)

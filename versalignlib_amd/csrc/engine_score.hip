@@ -22,8 +22,18 @@ void Engine::score_device(int opt, long long n, const uint8_t *d_reads, const ui
     // call then WAITS for the classification (the host lays the groups out); mode 1 sweeps the batch as it stands when
     // the length classes would not skip a third of the cells.
     if (length_sorted && ragged_applies(alg) && ragged_fits(n) && n >= 2 * ragged_min_) {
+        // One context (pinned histogram / tables, counters, packed buffers) serves the device-resident calls of this
+        // engine: a call on ANOTHER stream than the last one first waits, on the host, until that one's kernels and
+        // table copies are through -- otherwise it would rewrite the pinned tables under them.  Calls on one stream are
+        // ordered by the stream.
+        if (ragged_dev_done_ && ragged_dev_stream_ != stream)
+            hip_check(hipEventSynchronize(ragged_dev_done_), "hipEventSynchronize(previous length-sorted call)");
+        if (!ragged_dev_done_) hip_check(hipEventCreateWithFlags(&ragged_dev_done_, hipEventDisableTiming), "hipEventCreate");
+        ragged_dev_stream_ = stream;
         ragged_begin(kSlots, n, d_reads, d_refs, stream);           // (a context of its own: the pipeline's slots may be busy on the engine's streams)
-        if (ragged_finish(kSlots, alg, n, d_scores, stream, ragged_ == 2)) return;
+        const bool swept = ragged_finish(kSlots, alg, n, d_scores, stream, ragged_ == 2);
+        hip_check(hipEventRecord(ragged_dev_done_, stream), "hipEventRecord");
+        if (swept) return;
     }
     // a batch that leaves most SIMDs with at most one wave is over when its slowest wave is: shortest sweep
     const bool few = n <= (long long)latency_plan_.pairs_per_wave * 1024 && band_width_ == 0;
@@ -280,6 +290,8 @@ void Engine::ensure_ragged(int c, long long n) {
 }
 
 void Engine::release_ragged() {
+    if (ragged_dev_done_) (void)hipEventDestroy(ragged_dev_done_);
+    ragged_dev_done_ = nullptr;
     for (RaggedCtx &x : rag_) {
         for (void *p : {(void *)x.reads, (void *)x.refs, (void *)x.scores, (void *)x.bin, (void *)x.pos, (void *)x.place, (void *)x.counters, (void *)x.tables})
             if (p) (void)hipFree(p);

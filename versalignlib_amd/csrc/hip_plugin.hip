@@ -138,6 +138,19 @@ private:
     int cap_ = 0;
 };
 
+// hip_devices = N: the one rule by which a call's pairs are cut into contiguous shards -- `per` pairs each (the last one
+// short, trailing shards empty when n < N * per) -- used by the shard threads AND by the gather path's buffer offsets.
+struct ShardSplit {
+    int per;
+    ShardSplit(int n, int shards) : per(shards > 0 ? (n + shards - 1) / shards : n) {}
+    int begin(int d) const { return d * per; }
+    int count(int d, int n) const {
+        const int b = begin(d);
+        return b < n ? (n - b < per ? n - b : per) : 0;
+    }
+    int shard_of(int first_pair) const { return per > 0 ? first_pair / per : 0; }
+};
+
 // The kernel object handed to the host.  Reads the same six required keys as every
 // reference backend at construction (DefaultKernel.h:70-81) and num_threads per call
 // (DefaultKernel.cpp:45); the latter sizes the host gather pool here.
@@ -258,10 +271,11 @@ public:
             const int shards = 1 + (int)more_.size();
             if (gather_ && aln_number >= shards) {
                 // every device keeps its shard in HBM; the RCCL all-gather puts the whole vector on each of them
-                const int per = (aln_number + shards - 1) / shards;
+                const ShardSplit split(aln_number, shards);
+                const int per = split.per;
                 gather_->reserve(per);
                 sharded(aln_number, threads, [&](valign::Engine &e, int begin, int count, int th) {
-                    e.score_host(opt, count, reads + begin, refs + begin, nullptr, th, gather_->shard(begin / per));
+                    e.score_host(opt, count, reads + begin, refs + begin, nullptr, th, gather_->shard(split.shard_of(begin)));
                 });
                 gather_->gather_to_host(per, aln_number, scores);
                 log_line(0, "HIPKernel score done (RCCL all-gather of " + std::to_string(shards) + " shard(s) of " + std::to_string(per) +
@@ -312,11 +326,12 @@ private:
             fn(*engine_, 0, n, threads);
             return;
         }
-        const int per = (n + shards - 1) / shards, th = threads / shards > 0 ? threads / shards : 1;
+        const ShardSplit split(n, shards);
+        const int th = threads / shards > 0 ? threads / shards : 1;
         std::vector<std::exception_ptr> errors((size_t)shards);
         std::vector<std::thread> workers;
         for (int d = 0; d < shards; ++d) {
-            const int begin = d * per, count = begin < n ? (n - begin < per ? n - begin : per) : 0;
+            const int begin = split.begin(d), count = split.count(d, n);
             if (count <= 0) continue;
             valign::Engine *e = d == 0 ? engine_.get() : more_[(size_t)d - 1].get();
             workers.emplace_back([&, e, begin, count, d] {
@@ -380,6 +395,15 @@ VALIGN_EXPORT int valign_hip_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
     return count;
+}
+
+// (for tests, no device needed) shard d of a call of n pairs under hip_devices = shards: first pair and pair count
+VALIGN_EXPORT int valign_hip_shard_range(int n, int shards, int d, int *begin, int *count) {
+    if (n < 0 || shards < 1 || d < 0 || d >= shards || !begin || !count) return 1;
+    const ShardSplit split(n, shards);
+    *begin = split.begin(d);
+    *count = split.count(d, n);
+    return 0;
 }
 
 VALIGN_EXPORT int valign_hip_engine_create(int device, int read_length, int ref_length,

@@ -56,12 +56,12 @@ public:
             std::exception_ptr e = error_;
             error_ = nullptr;
             jobs_.clear();
-            for (int s = 0; s < 16; ++s) issued_[s] = submitted_[s];
+            for (int s = 0; s < kSlots; ++s) issued_[s] = submitted_[s];
             std::rethrow_exception(e);
         }
     }
     void wait_idle() {
-        for (int s = 0; s < 16; ++s) wait_issued(s);
+        for (int s = 0; s < kSlots; ++s) wait_issued(s);
     }
 
 private:
@@ -111,7 +111,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::vector<Job> jobs_;
-    long long submitted_[16] = {}, issued_[16] = {};
+    long long submitted_[kSlots] = {}, issued_[kSlots] = {};       // per staging slot of the engine's pipeline (Job::slot)
     bool stop_ = false;
     std::exception_ptr error_;
     std::thread thread_;            // last: starts when everything above exists

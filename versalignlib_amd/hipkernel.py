@@ -81,7 +81,7 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "spawn_alignment_kernel", "set_parameters", "set_logger", "delete_alignment_kernel",
-    "valign_hip_device_count", "valign_hip_engine_create", "valign_hip_engine_destroy",
+    "valign_hip_device_count", "valign_hip_shard_range", "valign_hip_engine_create", "valign_hip_engine_destroy",
     "valign_hip_set_traceback_policy", "valign_hip_set_pointer_scratch_cap_mb", "valign_hip_set_host_packing", "valign_hip_set_half_float_cells", "valign_hip_host_register", "valign_hip_host_unregister", "valign_hip_set_band_width", "valign_hip_set_score_width", "valign_hip_set_ragged_batching", "valign_hip_score_device", "valign_hip_align_device", "valign_hip_score_host", "valign_hip_align_host", "valign_hip_describe",
     "valign_hip_last_error",
 )
