@@ -7,7 +7,8 @@ O=gpurun_out/final_$TAG
 for f in pmc_final bench_final bench_long pmc_align pmc_long; do cp $O/$f.json profiles/${TAG}_$f.json; done
 cp $O/pmc_long_affine.json profiles/${TAG}_pmc_long_affine.json
 [ -f $O/pmc_long_c5.json ] && cp $O/pmc_long_c5.json profiles/${TAG}_pmc_long_c5.json
-for f in align_bench latency long_reads host_alloc; do cp $O/$f.txt profiles/${TAG}_$f.txt; done
+[ -f $O/pmc_long_c5_affine.json ] && cp $O/pmc_long_c5_affine.json profiles/${TAG}_pmc_long_c5_affine.json
+for f in align_bench latency long_reads d2h_rows_ab; do [ -f $O/$f.txt ] && cp $O/$f.txt profiles/${TAG}_$f.txt; done
 [ -f $O/pmc_align_dispatches.txt ] && cp $O/pmc_align_dispatches.txt profiles/${TAG}_pmc_align_dispatches.txt
 cp "$(ls -t $O/prof_bench/runc/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_kernel_stats.csv
 cp "$(ls -t $O/prof_align/runc/*kernel_stats.csv | head -1)" profiles/${TAG}_align_kernel_stats.csv

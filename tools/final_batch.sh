@@ -21,6 +21,8 @@ echo "bench trace done"
 bash tools/pmc_long.sh c5 --R 10000 --F 10000 --n 32768 --band 512 --width 32 > $OUT/pmc_long_c5.log 2>&1
 python tools/pmc_summary.py $R/gpurun_out/pmc_c5 32768 > $OUT/pmc_long_c5.json || exit 1
 cp $OUT/pmc_long_c5.json $R/profiles/${TAG}_pmc_long_c5.json
+bash tools/pmc_long.sh c5aff --R 10000 --F 10000 --n 32768 --band 512 --width 32 --affine 1 > $OUT/pmc_long_c5_affine.log 2>&1
+python tools/pmc_summary.py $R/gpurun_out/pmc_c5aff 32768 > $OUT/pmc_long_c5_affine.json || exit 1
 python bench.py --workload long --steps 5 --warmup 1 > $OUT/bench_long.json 2> $OUT/bench_long.err || exit 1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_long -- python3 $R/bench.py --workload long --steps 3 --warmup 1 --no-cpu > $OUT/prof_long.log 2>&1) || exit 1
 echo "long bench done"
@@ -34,12 +36,15 @@ echo "align pmc done"
   echo "# tools/latency_bench.py 1 (plugin ABI, num_threads = 1)"; python tools/latency_bench.py 1;
   echo "# tools/latency_bench.py 16 (plugin ABI, num_threads = 16: result rows of calls above 768 KB are copied by the pool)"; python tools/latency_bench.py 16;
   echo "# tools/first_call.py: cold process -> first results, and a second spawn in the warm process"; python tools/first_call.py; } 2>&1 | grep -v amdgpu.ids > $OUT/latency.txt || exit 1
-{ echo "# long reads: 2.5k x 5k (65536 pairs), 10k x 10k (32768 pairs = one GPU's share of BASELINE config 5), banded (512), affine";
+{ echo "# long reads: 2.5k x 5k (65536 pairs), 10k x 10k (32768 pairs = one GPU's share of BASELINE config 5), banded (512), affine; then the round-3 schedules of the same (VALIGN_HIP_DEBUG=short_strips / no_band_chain)";
   python tools/geom_sweep.py --R 2500 --F 5000 --n 65536 --iters 2 --geoms 0x0;
   python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0;
   python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --band 512;
   python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --affine 1;
   python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --affine 1 --band 512;
+  VALIGN_HIP_DEBUG=short_strips python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0;
+  VALIGN_HIP_DEBUG=short_strips python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --affine 1;
+  VALIGN_HIP_DEBUG=no_band_chain python tools/geom_sweep.py --R 10000 --F 10000 --n 32768 --iters 1 --geoms 0x0 --affine 1 --band 512;
   echo "# affine with four different scores (SW), NW affine, 150 x 500";
   python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 2;
   python tools/geom_sweep.py --n 1048576 --geoms 0x0 --affine 1 --opt 1; } 2>&1 | grep -v amdgpu.ids > $OUT/long_reads.txt || exit 1
@@ -47,4 +52,5 @@ echo "sweeps done"
 bash tools/pmc_long.sh long_lin > $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_lin 65536 > $OUT/pmc_long.json
 bash tools/pmc_long.sh long_aff --affine 1 >> $OUT/pmc_long.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_long_aff 65536 > $OUT/pmc_long_affine.json
 echo "long pmc done"
+{ echo "# tools/align_d2h_ab.py 16 / 6 (host threads): result rows packed on the device vs whole rows vs registered destination"; python tools/align_d2h_ab.py 16; python tools/align_d2h_ab.py 6; } 2>&1 | grep -v amdgpu.ids > $OUT/d2h_rows_ab.txt
 echo "all done"
