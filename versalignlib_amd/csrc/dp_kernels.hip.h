@@ -404,36 +404,11 @@ __device__ __forceinline__ void fetch_profile(unsigned addr_a, unsigned addr_b, 
     merge_profile<K>(va, vb, S);
 }
 
-// Profile fetch WITHOUT the merge instruction (tuning switch, OFF: measured slower, see below): the K scores of
-// pair A are loaded straight into the low halves and those of pair B into the high halves of the K packed registers
-// with 16-bit LDS loads that leave the other half of the destination alone (ds_read_u16_d16 / _d16_hi).  That removes
-// the v_perm_b32 per register of merge_profile -- the hot loop drops from 217 to 197 VALU instructions per step pair
-// (int16 affine) and from 187 to 167 (half floats) -- but 2K narrow loads per step instead of ~K/2 wide ones cost
-// more than the 10 % VALU they save: 1 M pairs 150 x 500, MI355X, round 2: int16 affine 13.10 -> 13.54 ms, half-float
-// affine 11.47 -> 12.14 ms, linear 7.19 -> 8.66 ms (gpurun_out r02_bench_a vs r02_bench_b).  Every LDS return
-// writes a full wave of VGPRs whatever its width, and that write traffic competes with the VALU.
-// The loads are inline asm, so the compiler does not count them: profile_wait() is the s_waitcnt before the first
-// use (its own waits only become more conservative with extra operations in flight: LDS returns in order).
-#ifndef VALIGN_D16_PROFILE
-#define VALIGN_D16_PROFILE 0
-#endif
-constexpr bool kD16Profile = VALIGN_D16_PROFILE != 0;
-
-template <int K>
-__device__ __forceinline__ void profile_load_d16(unsigned addr_a, unsigned addr_b, s16x2 (&S)[K]) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-        asm volatile("ds_read_u16_d16 %0, %1 offset:%2" : "+v"(S[q]) : "v"(addr_a), "n"(2 * q));
-        asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(S[q]) : "v"(addr_b), "n"(2 * q));
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void profile_wait(s16x2 (&S)[K]) {
-    asm volatile("s_waitcnt lgkmcnt(0)");
-#pragma unroll
-    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(S[q]));      // every use of S[q] stays behind the wait
-}
+// (Round 2 also tried fetching the profile WITHOUT the merge instruction -- ds_read_u16_d16 / _d16_hi straight into the
+// register halves, which removes the v_perm_b32 per register (hot loop 217 -> 197 VALU per step pair, int16 affine): 2K
+// narrow LDS returns per step instead of ~K/2 wide ones cost more than the 10 % VALU they save -- int16 affine 13.10 ->
+// 13.54 ms, half-float affine 11.47 -> 12.14 ms, linear 7.19 -> 8.66 ms: every LDS return writes a full wave of VGPRs
+// whatever its width.  The code is gone; DESIGN.md section 3 keeps the numbers.)
 
 // GAPS selects the recurrence: kGapLinear (two gap scores), kGapSym (linear with
 // gap_read == gap_ref: one subtract serves both neighbours), kGapAffine (Gotoh extension).
@@ -600,18 +575,12 @@ score_kernel(const ScoreArgs args) {
     // at one wave per SIMD).
     constexpr bool PIPE = true;
     unsigned pa[K / 2], pb[K / 2];
-    s16x2 S0[K], S1[K];          // kD16Profile: the scores of this step and of the next, roles swap every step
+    s16x2 S0[K], S1[K];          // the scores of a step (two buffers: the steady loop takes two steps per trip)
     unsigned ca_next = 0, cb_next = 0;
     if (PIPE) {
         const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
-        if (kD16Profile) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) S0[q] = S1[q] = pk(0);
-            profile_load_d16<K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S0);
-        } else {
-            lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
-            lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
-        }
+        lds_load_lane<K>(lane_base + ca * geo::kPairStride, pa);
+        lds_load_lane<K>(lane_base + cb * geo::kPairStride, pb);
         ca_next = *(lds_cu8 *)(code_addr + 2);
         cb_next = *(lds_cu8 *)(code_addr + 3);
     }
@@ -641,14 +610,9 @@ score_kernel(const ScoreArgs args) {
         s16x2 gup0 = pk(0);        // kGapSymF16 (SW): max(h + g, 0) of the row above
         if (LINF16_SW) gup0 = as_pk(from_prev_lane(as_u32(f_last)) & lmask);
         if (PIPE) {
-            if (kD16Profile) {
-                profile_wait<K>(S);                                              // step t's scores have landed
-                profile_load_d16<K>(lane_base + ca_next * geo::kPairStride, lane_base + cb_next * geo::kPairStride, Snext);
-            } else {
-                merge_profile<K>(pa, pb, S);                                     // step t's scores
-                lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows
-                lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
-            }
+            merge_profile<K>(pa, pb, S);                                     // step t's scores
+            lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows
+            lds_load_lane<K>(lane_base + cb_next * geo::kPairStride, pb);
             ca_next = *(lds_cu8 *)(code_addr + 4);                            // step t+2's slab numbers
             cb_next = *(lds_cu8 *)(code_addr + 5);
         }
@@ -829,15 +793,7 @@ score_kernel(const ScoreArgs args) {
     using all_t = std::integral_constant<int, kTrackAll>;
     using first_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackNone : kTrackAll>;
     using second_t = std::integral_constant<int, (SYM && ALG == kAlgSW) ? kTrackPair : kTrackAll>;
-    // a lone step consumes S0 and fills S1: the scores move back (d16 fetch; only in the short fill / drain phases)
-    auto single = [&](auto masked_tag) __attribute__((always_inline)) {
-        step(masked_tag, all_t{}, S0, S1);
-        if (kD16Profile) {
-            profile_wait<K>(S1);                   // the copy reads registers the loads of this step are still filling
-#pragma unroll
-            for (int q = 0; q < K; ++q) S0[q] = S1[q];
-        }
-    };
+    auto single = [&](auto masked_tag) __attribute__((always_inline)) { step(masked_tag, all_t{}, S0, S1); };
     for (; t < fill_end; ++t) single(std::true_type{});
     {                                          // two steps per trip: loop-carried registers swap roles
         for (; t + 1 < steady_end; t += 2) {   // instead of being copied (+4 % SW, +10 % NW linear,
