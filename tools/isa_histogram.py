@@ -3,7 +3,8 @@
 
     python tools/isa_histogram.py --part 5 --kernel 'align_fill_affine_tag_kernelILi16ELi10ELi1ELb1'
 
-compiles versalignlib_amd/csrc/kernel_part.hip (-DVALIGN_PART=n) or hip_plugin.hip (--part main) for gfx950 with
+compiles versalignlib_amd/csrc/kernel_part.hip (-DVALIGN_PART=n), engine_long.hip (--part main: band / long-read kernels) or
+engine_align.hip (--part align: strip / fused / traceback kernels) for gfx950 with
 --cuda-device-only -S, finds the largest innermost loop of the first kernel whose mangled name contains --kernel, and
 counts its instructions by issue class.  Classes follow the measured rates of profiles/r02_valu_rate_microbench.txt and
 r02_valu_rate_bitops.txt: "full" (2.3-2.7 cycles per wave64 instruction per SIMD from two waves per SIMD up) and
@@ -47,10 +48,10 @@ def main():
     asm = a.asm
     if not asm:
         asm = os.path.join(tempfile.gettempdir(), "valign_part_%s.s" % a.part)
-        src = "hip_plugin.hip" if a.part == "main" else "kernel_part.hip"
+        src = "engine_long.hip" if a.part == "main" else ("engine_align.hip" if a.part == "align" else "kernel_part.hip")
         cmd = ["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
                "-I" + CSRC, os.path.join(CSRC, src), "-o", asm]
-        if a.part != "main":
+        if a.part not in ("main", "align"):
             cmd.insert(5, "-DVALIGN_PART=%s" % a.part)
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     lines = open(asm).read().split("\n")

@@ -54,7 +54,8 @@ struct BandArgs {
     const int *fill_to;         // per event: the reference ring must hold every column below this one
     long long n;
     int R, F;
-    int nb;                     // real blocks = strips * kBandG
+    int nb;                     // blocks = strips * kBandG
+    int first_block;            // the first block that holds a row of the read (the ones before it are top padding: skipped)
     int pad_rows;               // padding rows above the read (class "none")
     int d;                      // steps between block starts
     int ring_depth;             // delay ring slots per lane (power of two > every delay)
@@ -200,12 +201,15 @@ score_band_kernel(const BandArgs args) {
         if (c1 < limit) codes[grp * args.code_cols + (c1 & code_mask)] = (unsigned char)slab_of(b1);
     };
 
-    // before the first event: the ring up to fill_to[0] (synchronously, once), block 0's read bases
+    // before the first event: the ring up to the first block's fill target (synchronously, once), that block's read bases.
+    // The chain starts with the first block that holds a row of the read: the blocks of top padding before it (15 of 640
+    // at 10 kbp) would only cost their d steps each.
+    const int b0 = args.first_block;
     int filled = 0;
-    for (; filled < args.fill_to[0]; filled += 2 * kBandG)
-        commit_codes(filled, args.fill_to[0], ref_base(filled), ref_base(filled + kBandG));
-    filled = args.fill_to[0];
-    unsigned pre_row0 = row_base(rows0, 0), pre_row1 = row_base(rows1, 0);
+    for (; filled < args.fill_to[b0]; filled += 2 * kBandG)
+        commit_codes(filled, args.fill_to[b0], ref_base(filled), ref_base(filled + kBandG));
+    filled = args.fill_to[b0];
+    unsigned pre_row0 = row_base(rows0, b0), pre_row1 = row_base(rows1, b0);
     unsigned pre_ref0 = 0, pre_ref1 = 0;
     int pre_first = filled, pre_limit = filled;
 
@@ -332,7 +336,7 @@ score_band_kernel(const BandArgs args) {
     // ================= event: block b starts on lane b % G of both groups =================
     // The switching lane's first step is its warm-up column (inactive: the scores in flight for it may be anything);
     // what must be right is the slab of the step after, read here.  Nobody else's pipeline is touched.
-    int b = 0;
+    int b = b0;
     auto event = [&]() __attribute__((always_inline)) {
         const int ls = b % kBandG;
         const BandBlock blk = args.blocks[b];                             // (uniform: scalar loads)
@@ -374,7 +378,7 @@ score_band_kernel(const BandArgs args) {
 
     // the last blocks need a full period to finish; two steps per trip (the score registers swap roles), the event
     // due before either of them
-    const int total_steps = (args.nb + kBandG) * d;
+    const int total_steps = (args.nb - b0 + kBandG) * d;
     int next_event = 0;
     for (int t = 0; t < total_steps; t += 2) {
         if (t == next_event) {

@@ -304,7 +304,7 @@ public:
 
     struct BandPlan {
         bool usable = false, unit_delay = false;
-        int nb = 0, pad_rows = 0, d = 0, ring_depth = 0, code_cols = 0, events = 0;
+        int nb = 0, first_block = 0, pad_rows = 0, d = 0, ring_depth = 0, code_cols = 0, events = 0;
         long long cells = 0;                // DP cells one pair's band windows hold (what the chain actually sweeps)
         std::vector<BandBlock> blocks;
         std::vector<int> fill_to;

@@ -59,6 +59,7 @@ Engine::BandPlan Engine::make_band_plan() const {
         hi[(size_t)b] = (int)std::min<long long>((long long)r_hi * F / R + w, F - 1);
     }
     for (int b = 0; b < first_real; ++b) start[(size_t)b] = start[(size_t)first_real];
+    p.first_block = std::max(first_real, 0);
     int width = 1, dmax = 0, dmin = 1 << 30;
     for (int b = 0; b < p.nb; ++b) {
         width = std::max(width, hi[(size_t)b] - start[(size_t)b] + 1);
@@ -147,6 +148,7 @@ bool Engine::score_band_device(long long n, const uint8_t *d_reads, const uint8_
     a.R = R_;
     a.F = F_;
     a.nb = p.nb;
+    a.first_block = p.first_block;
     a.pad_rows = p.pad_rows;
     a.d = p.d;
     a.ring_depth = p.ring_depth;
