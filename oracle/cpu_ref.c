@@ -483,116 +483,6 @@ typedef struct {
     uint8_t e_ext;  /* E(i,j) extended E(i,j-1) (1) or opened from H(i,j-1) (0)   */
 } aff_ptr;
 
-static void affine_fill(int alg, const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
-                        const vref_scoring *sc, int16_t *Hrow, int16_t *Frow, aff_ptr *ptr, int *end_i, int *end_j) {
-    const int16_t oR = (int16_t)sc->open_read, eR = (int16_t)sc->ext_read;
-    const int16_t oF = (int16_t)sc->open_ref, eF = (int16_t)sc->ext_ref;
-    for (int j = 0; j <= F; ++j) { Hrow[j] = 0; Frow[j] = NEG_INF; }
-    int16_t best = 0; int bi = 0, bj = 0;
-    int16_t last_read = (int16_t)(R - 1), last_ref = (int16_t)(F - 1);
-    int16_t row_best = INT16_MIN, row_arg = 0, snap_arg = -1;
-    for (int i = 0; i < R; ++i) {
-        const int16_t *srow = tab[g_class[read[i]]];
-        aff_ptr *prow = ptr + (size_t)(i + 1) * (F + 1);
-        int16_t hdiag = Hrow[0];
-        int16_t hleft = 0;
-        if (alg == 1) {
-            hleft = (int16_t)(oF + i * eF);                 /* H(i+1, 0) */
-            prow[0].h = 2; prow[0].f_ext = (uint8_t)(i > 0); prow[0].e_ext = 0;
-            if (last_read == R - 1 && g_class[read[i]] == 0) last_read = (int16_t)(i - 1);
-            if (last_read + 1 == i) snap_arg = row_arg;
-            row_best = hleft; row_arg = 0;
-        }
-        const int16_t hcol0 = hleft;
-        int16_t e = NEG_INF;
-        for (int j = 0; j < F; ++j) {
-            const int16_t hup = Hrow[j + 1];
-            const int16_t e_open = sat_add(hleft, oR), e_extd = sat_add(e, eR);
-            const int16_t f_open = sat_add(hup, oF), f_extd = sat_add(Frow[j + 1], eF);
-            e = max16(e_extd, e_open);
-            const int16_t f = max16(f_extd, f_open);
-            const int16_t diag = (int16_t)(hdiag + srow[g_class[ref[j]]]);
-            int16_t h = max16(max16(diag, e), f);
-            if (alg == 0) h = max16(h, 0);
-            aff_ptr p;
-            p.f_ext = (uint8_t)(f != f_open);
-            p.e_ext = (uint8_t)(e != e_open);
-            if (alg == 0 && h == 0) p.h = 0;
-            else if (h == diag) p.h = 1;
-            else if (h == f) p.h = 2;
-            else p.h = 3;
-            prow[j + 1] = p;
-            if (alg == 0) {
-                if (h > best) { best = h; bi = i; bj = j; }
-            } else {
-                if (last_ref == F - 1 && g_class[ref[j]] == 0) last_ref = (int16_t)(j - 1);
-                if (h > row_best) { row_best = h; row_arg = (int16_t)j; }
-            }
-            Frow[j + 1] = f;
-            hdiag = hup;
-            Hrow[j + 1] = h;
-            hleft = h;
-        }
-        Hrow[0] = hcol0;
-    }
-    if (alg == 0) { *end_i = bi; *end_j = bj; }
-    else {
-        if (snap_arg < 0) snap_arg = row_arg;
-        *end_i = last_read;
-        *end_j = last_ref < snap_arg ? last_ref : snap_arg;
-    }
-}
-
-int vref_align_affine(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
-                      const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
-    class_init();
-    if ((opt & 0xF) > 1) return 0;
-    int16_t tab[6][6];
-    subst_init(sc, tab);
-    const int alg = opt & 0xF, AL = R + F;
-    if (threads < 1) threads = 1;
-#pragma omp parallel num_threads(threads)
-    {
-        int16_t *Hrow = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
-        int16_t *Frow = (int16_t *)malloc(sizeof(int16_t) * (size_t)(F + 1));
-        aff_ptr *ptr = (aff_ptr *)malloc(sizeof(aff_ptr) * (size_t)(R + 1) * (F + 1));
-#pragma omp for schedule(static)
-        for (int p = 0; p < n; ++p) {
-            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
-            memset(ptr, 0, sizeof(aff_ptr) * (size_t)(R + 1) * (F + 1));      /* row 0: START */
-            int rp, fp;
-            affine_fill(alg, rd, rf, R, F, tab, sc, Hrow, Frow, ptr, &rp, &fp);
-            uint8_t *row_read = rows_out + (size_t)p * 2 * AL, *row_ref = row_read + AL;
-            memset(row_read, 0, (size_t)AL);
-            memset(row_ref, 0, (size_t)AL);
-            int k = AL - 2, state = 0;                      /* 0 at H, 2 inside F, 3 inside E */
-            for (;;) {
-                const aff_ptr q = ptr[(size_t)(rp + 1) * (F + 1) + fp + 1];
-                if (state == 0) {
-                    if (q.h == 0) break;
-                    if (q.h == 1) { row_read[k] = rd[rp--]; row_ref[k] = rf[fp--]; --k; }
-                    else state = q.h;                       /* enter the gap state, nothing emitted yet */
-                } else if (state == 2) {
-                    row_read[k] = rd[rp]; row_ref[k] = '-'; --k;
-                    state = q.f_ext ? 2 : 0;
-                    --rp;
-                } else {
-                    row_read[k] = '-'; row_ref[k] = rf[fp]; --k;
-                    state = q.e_ext ? 3 : 0;
-                    --fp;
-                }
-            }
-            int16_t *idx = idx_out + (size_t)p * 4;
-            idx[0] = (int16_t)(k + 1); idx[1] = (int16_t)(AL - 1);
-            idx[2] = (int16_t)(k + 1); idx[3] = (int16_t)(AL - 1);
-        }
-        free(ptr);
-        free(Frow);
-        free(Hrow);
-    }
-    return n;
-}
-
 /* ---- second tie-break policy: the reference's SSE2 / AVX2 kernels ----
  * Same cell values, different pointers (src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 646-659):
  *   pointer = DIAG if the cell equals diag+S AND both bases are in ACGT, else LEFT if it equals
@@ -604,79 +494,31 @@ int vref_align_affine(int opt, int n, int R, int F, const uint8_t *reads, const 
  *   UP (NW) / START (SW).                                                                    */
 static int valid_acgt(uint8_t ch) { const int c = g_class[ch]; return c >= 1 && c <= 4; }
 
-static void sse_fill(int alg, const uint8_t *read, const uint8_t *ref, int R, int F, int16_t tab[6][6],
-                     int16_t gr, int16_t gf, int16_t *rows, uint8_t *ptr, int *end_i, int *end_j) {
-    int16_t *prev = rows, *cur = rows + (F + 1);
-    memset(rows, 0, sizeof(int16_t) * 2 * (size_t)(F + 1));
-    int16_t best = 0; int bi = 0, bj = 0;
-    int16_t last_read = (int16_t)(R - 1), last_ref = (int16_t)(F - 1);
-    int16_t row_best = INT16_MIN, row_arg = 0, snap_arg = -1;
-    for (int i = 0; i < R; ++i) {
-        uint8_t *prow = ptr + (size_t)(i + 1) * (F + 1);
-        const int vr = valid_acgt(read[i]);
-        if (alg == 1) {
-            prow[0] = PTR_UP;
-            cur[0] = (int16_t)((i + 1) * gf);
-            if (last_read == R - 1 && !vr) last_read = (int16_t)(i - 1);
-            if (last_read + 1 == i) snap_arg = row_arg;
-            row_best = cur[0]; row_arg = 0;
-        }
-        const int16_t *srow = tab[g_class[read[i]]];
-        for (int j = 0; j < F; ++j) {
-            const int16_t up = (int16_t)(prev[j + 1] + gf), left = (int16_t)(cur[j] + gr);
-            const int16_t diag = (int16_t)(prev[j] + srow[g_class[ref[j]]]);
-            int16_t h = max16(diag, max16(left, up));
-            if (alg == 0) h = max16(h, 0);
-            cur[j + 1] = h;
-            uint8_t p = PTR_START;
-            if (h == up) p = PTR_UP;
-            if (h == left) p = PTR_LEFT;
-            if (h == diag && vr && valid_acgt(ref[j])) p = PTR_DIAG;
-            prow[j + 1] = p;
-            if (alg == 0) {
-                if (h > best) { best = h; bi = i; bj = j; }
-            } else {
-                if (last_ref == F - 1 && !valid_acgt(ref[j])) last_ref = (int16_t)(j - 1);
-                if (h > row_best) { row_best = h; row_arg = (int16_t)j; }
-            }
-        }
-        int16_t *t = prev; prev = cur; cur = t;
-    }
-    if (alg == 0) { *end_i = bi; *end_j = bj; }
-    else {
-        if (snap_arg < 0) snap_arg = row_arg;
-        *end_i = last_read;
-        *end_j = last_ref < snap_arg ? last_ref : snap_arg;
-    }
-}
 
-int vref_align_sse(int opt, int n, int R, int F, const uint8_t *reads, const uint8_t *refs,
-                   const vref_scoring *sc, uint8_t *rows_out, int16_t *idx_out, int threads) {
-    class_init();
-    if ((opt & 0xF) > 1) return 0;
-    int16_t tab[6][6];
-    subst_init(sc, tab);
-    const int16_t gr = (int16_t)sc->gap_read, gf = (int16_t)sc->gap_ref;
-    const int alg = opt & 0xF, AL = R + F;
-    if (threads < 1) threads = 1;
-#pragma omp parallel num_threads(threads)
-    {
-        int16_t *rows = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(F + 1));
-        uint8_t *ptr = (uint8_t *)malloc((size_t)(R + 1) * (F + 1));
-#pragma omp for schedule(static)
-        for (int p = 0; p < n; ++p) {
-            const uint8_t *rd = reads + (size_t)p * R, *rf = refs + (size_t)p * F;
-            memset(ptr, PTR_START, (size_t)(R + 1) * (F + 1));
-            int ei, ej;
-            sse_fill(alg, rd, rf, R, F, tab, gr, gf, rows, ptr, &ei, &ej);
-            traceback(rd, rf, R, F, ptr, ei, ej, rows_out + (size_t)p * 2 * AL,
-                      rows_out + (size_t)p * 2 * AL + AL, idx_out + (size_t)p * 4);
-        }
-        free(ptr);
-        free(rows);
-    }
-    return n;
-}
+#define VMAX(a, b) ((a) > (b) ? (a) : (b))
+#define VCELL int16_t
+#define VNAME(x) x
+#define VADD(a, b) sat_add(a, b)
+#define VNINF NEG_INF
+#define VMIN INT16_MIN
+#include "cpu_ref_fills.inc"
+#undef VCELL
+#undef VNAME
+#undef VADD
+#undef VNINF
+#undef VMIN
+/* int32 cells: vref_align_affine_wide, vref_align_sse_wide */
+#define VCELL int32_t
+#define VNAME(x) x##_wide
+#define VADD(a, b) ((a) + (b))
+#define VNINF (-(1 << 29))
+#define VMIN INT32_MIN
+#include "cpu_ref_fills.inc"
+#undef VCELL
+#undef VNAME
+#undef VADD
+#undef VNINF
+#undef VMIN
 
 /* ---- banded Smith-Waterman score (extension: the reference has no banding) ----
  * DEFINITION (include/valign_hip.h, "band_width"): the read's rows are taken in blocks of `block_rows`

@@ -97,7 +97,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, i16p, ctypes.c_int]
-        for name in ("vref_align", "vref_align_affine", "vref_align_sse", "vref_align_wide"):
+        for name in ("vref_align", "vref_align_affine", "vref_align_sse", "vref_align_wide", "vref_align_affine_wide", "vref_align_sse_wide"):
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_int] * 4 + [u8p, u8p, sp, u8p, i16p, ctypes.c_int]
@@ -156,14 +156,20 @@ def score_banded_sw(reads, refs, band_width, scoring=None, threads=1, block_rows
 
 def align(opt, reads, refs, scoring=None, threads=1, affine=False, policy="default", wide=False):
     """-> rows uint8 [n,2,R+F] (zero before start, NUL at R+F-1), idx int16 [n,4].
-    wide: int32 cells (linear gaps, default tie-breaks) -- identical wherever int16 does not overflow."""
+    wide: int32 cells (every model and policy) -- identical wherever int16 does not overflow."""
     reads, refs = _check(reads, refs)
     sc = scoring or Scoring.make()
     n, R = reads.shape
     F = refs.shape[1]
     rows = np.zeros((n, 2, R + F), dtype=np.uint8)
     idx = np.zeros((n, 4), dtype=np.int16)
-    fn = lib().vref_align_affine if affine else (lib().vref_align_sse if policy == "sse" else (lib().vref_align_wide if wide else lib().vref_align))
+    L = lib()
+    if affine:
+        fn = L.vref_align_affine_wide if wide else L.vref_align_affine
+    elif policy == "sse":
+        fn = L.vref_align_sse_wide if wide else L.vref_align_sse
+    else:
+        fn = L.vref_align_wide if wide else L.vref_align
     fn(opt, n, R, F, _u8(reads), _u8(refs), ctypes.byref(sc), _u8(rows),
        idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), threads)
     return rows, idx

@@ -347,10 +347,10 @@ def test_affine_alignments_of_long_reads(R, F, n, seed, aff):
     keys = dict(score_gap_open_read=aff[0], score_gap_extend_read=aff[1], score_gap_open_ref=aff[2], score_gap_extend_ref=aff[3])
     with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, **keys) as hip:
         for opt in (host.SW, host.NW):
-            if opt == host.NW and (min(R, F) + 2) * min(aff) < -15000:
-                continue                      # cells of the NW variant would leave the affine int16 range: refused
+            # (cells of the NW variant that would leave the affine int16 range: int32 cells since round 4, refused before)
+            wide = opt == host.NW and (min(R, F) + 2) * min(aff) < -15000
             got = hip.compute_alignments(opt, reads, refs, normalise=False)
-            _same_alignments(got, cpu_ref.align(opt, reads, refs, sc, threads=8, affine=True), (R, F, aff, opt))
+            _same_alignments(got, cpu_ref.align(opt, reads, refs, sc, threads=8, affine=True, wide=wide), (R, F, aff, opt))
             if aff[0] == aff[1] and aff[2] == aff[3]:
                 _same_alignments(got, cpu_ref.align(opt, reads, refs, cpu_ref.Scoring.make(2, -1, aff[0], aff[2]), threads=8),
                                  ("degenerate", opt))
@@ -412,8 +412,70 @@ def test_nw_alignments_on_int32_cells_where_int16_would_wrap():
         got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
         _same_alignments(got, cpu_ref.align(host.NW, reads, refs, sc, threads=4, wide=True), ("int32 NW", R, F))
     with host.Plugin(build.HIP_PLUGIN, R, F, score_gap_read=-2, score_gap_ref=-4, traceback_policy=1) as hip:
-        with pytest.raises(host.PluginError, match="int16"):          # the SSE rules exist on int16 cells only: still refused
-            hip.compute_alignments(host.NW, reads, refs)
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)     # (refused up to round 3: the SSE rules on int32 cells)
+        _same_alignments(got, cpu_ref.align(host.NW, reads, refs, sc, threads=4, policy="sse", wide=True), ("int32 NW, SSE rules", R, F))
+
+
+_WIDE_MODES = {
+    "linear": (dict(), dict(), dict()),
+    "affine": (dict(score_gap_open_read=-7, score_gap_extend_read=-2, score_gap_open_ref=-6, score_gap_extend_ref=-1), dict(affine=True), dict()),
+    "sse": (dict(traceback_policy=1), dict(policy="sse"), dict()),
+}
+
+
+def _wide_case(mode, scale, gaps=(-3, -4)):
+    """Plugin keys and oracle scoring of one int32 case: scores of the mode multiplied by `scale`."""
+    keys, okw, _ = _WIDE_MODES[mode]
+    keys = {k: (v * scale if k.startswith("score_") else v) for k, v in keys.items()}
+    keys.update(score_match=2 * scale, score_mismatch=-1 * scale, score_gap_read=gaps[0] * scale, score_gap_ref=gaps[1] * scale)
+    aff = [keys.get(k, None) for k in ("score_gap_open_read", "score_gap_extend_read", "score_gap_open_ref", "score_gap_extend_ref")]
+    sc = cpu_ref.Scoring.make(2 * scale, -1 * scale, gaps[0] * scale, gaps[1] * scale, *aff)
+    return keys, sc, okw
+
+
+@pytest.mark.parametrize("mode", ["linear", "affine", "sse"])
+@pytest.mark.parametrize("alg", [0, 1])
+@pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 171), (33, 70, 101, 173), (1, 1, 5, 174), (700, 90, 40, 175), (1030, 300, 9, 176),
+                                         (2049, 1500, 5, 177)])
+def test_int32_alignment_cells_every_mode_forced(monkeypatch, mode, alg, R, F, n, seed):
+    """Every mode of compute_alignments on the int32 strip kernel (VALIGN_HIP_DEBUG wide_align) on shapes where int16
+    suffices: identical to the oracle's int16 restatement (which the golden vectors pin) -- one strip and several (512 rows
+    each), odd pair counts, padding, invalid bases moving the end cell."""
+    debug_switches(monkeypatch, wide_align=1)
+    reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.03, n_run_frac=0.1, short_frac=0.15, lowercase_frac=0.05, junk_frac=0.05)
+    keys, sc, okw = _wide_case(mode, 1)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=3, **keys) as hip:
+        got = hip.compute_alignments(alg, reads, refs, normalise=False)
+    exp = cpu_ref.align(alg, reads, refs, sc, threads=8, **okw)
+    _same_alignments(got, exp, ("forced int32", mode, alg, R, F))
+    _same_alignments(exp, cpu_ref.align(alg, reads, refs, sc, threads=8, wide=True, **okw), "oracle int16 == int32")
+
+
+@pytest.mark.parametrize("mode", ["linear", "affine", "sse"])
+@pytest.mark.parametrize("alg", [0, 1])
+def test_alignments_whose_cells_leave_int16_every_mode(mode, alg):
+    """Scores large enough that Smith-Waterman cells pass 32767 (and 65535: the end value's high half travels in
+    EndCell.pad) and NW-variant cells fall below -32768 -- the reference's shorts wrap there, rounds 1-3 refused everything
+    but linear-gap NW.  Against the oracle's int32 restatement of the same rules; the same scores divided by the scale
+    give the same alignments on int16 cells."""
+    scale = 150
+    for R, F, n, seed in ((600, 900, 21, 181), (1300, 700, 7, 182)):
+        reads, refs = synth.make_pairs(n, R, F, seed=seed, sub_rate=0.08, indel_rate=0.02, n_run_frac=0.1, short_frac=0.2)
+        keys, sc, okw = _wide_case(mode, scale)
+        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, **keys) as hip:
+            got = hip.compute_alignments(alg, reads, refs, normalise=False)
+        _same_alignments(got, cpu_ref.align(alg, reads, refs, sc, threads=8, wide=True, **okw), ("int32", mode, alg, R, F))
+        keys1, sc1, _ = _wide_case(mode, 1)
+        _same_alignments(got, cpu_ref.align(alg, reads, refs, sc1, threads=8, **okw), ("scores / scale on int16", mode, alg, R, F))
+
+
+def test_alignment_scores_beyond_int32_bound_refused():
+    """(R + F) * |score| near 2^28: refused with a message, as every range check."""
+    R, F = 16000, 16000
+    reads, refs = synth.make_pairs(2, R, F, seed=191)
+    with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20000, score_mismatch=-20000, score_gap_read=-20000, score_gap_ref=-20000) as hip:
+        with pytest.raises(host.PluginError, match="int32"):
+            hip.compute_alignments(host.SW, reads, refs)
 
 
 @pytest.mark.parametrize("R,F,n,seed", [(150, 500, 203, 71), (64, 128, 300, 72), (33, 70, 101, 73), (1, 1, 5, 74), (700, 90, 40, 75),

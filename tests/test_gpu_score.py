@@ -203,13 +203,14 @@ def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
 
 
 def test_int16_range_is_checked_per_call():
-    """A shape whose cells could leave int16 never wraps silently (as the reference would): scores
-    move to int32 cells, alignments (int16 only) are refused loudly."""
+    """A shape whose cells could leave int16 never wraps silently (as the reference would): scores and (since round 4, every
+    mode) alignments move to int32 cells."""
     R, F = 2000, 2000
     reads, refs = _data(R, F, 4, 81)
     with host.Plugin(build.HIP_PLUGIN, R, F, score_match=20) as hip:     # 2000 * 20 > 32000
-        with pytest.raises(host.PluginError, match="int16 range"):
-            hip.compute_alignments(0, reads, refs)
+        rows, idx = hip.compute_alignments(0, reads, refs, normalise=False)
+        exp_rows, exp_idx = cpu_ref.align(0, reads, refs, cpu_ref.Scoring.make(20, -1, -3, -3), threads=8, wide=True)
+        assert np.array_equal(idx, exp_idx) and np.array_equal(rows, exp_rows)
         got = hip.score_alignments(0, reads, refs)
         assert np.array_equal(got, cpu_ref.score(0, reads, refs, cpu_ref.Scoring.make(20, -1, -3, -3), threads=8, wide=True))
     with host.Plugin(build.HIP_PLUGIN, R, F) as hip:                      # default scores fit

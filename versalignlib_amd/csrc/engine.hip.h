@@ -606,7 +606,7 @@ private:
     bool no_prof_key_ = dbg_.on("no_prof_key");   // compute the SW lane key instead of carrying it in the profile
     bool copy_engines_primed_ = false;
     std::unique_ptr<CopyIssuer> copy_issuer_;
-    bool wide_align_ = dbg_.on("wide_align");         // NW alignments (linear gaps, default tie-breaks) on int32 cells always
+    bool wide_align_ = dbg_.on("wide_align");         // alignments on int32 cells always (align_strip_wide_kernel)
     bool whole_rows_ = dbg_.on("whole_rows");         // result rows cross PCIe whole (A/B of the device-side packing)
     bool no_direct_out_ = dbg_.on("no_direct_out");   // stage + scatter even into registered result buffers
     bool no_overlap_ = dbg_.on("no_overlap");   // tracebacks in stream order behind their fills

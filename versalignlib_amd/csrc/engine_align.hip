@@ -14,23 +14,35 @@ struct StripGeometry {
     const void *kernel[2];
     const void *affine_kernel[2];      // nullptr: too many rows per lane for the affine kernel's registers
     const void *sse_kernel[2];         // traceback_policy = 1 (linear gaps)
-    const void *wide_kernel;           // NW variant on int32 cells (linear gaps, default tie-breaks); nullptr: too many registers
+    const void *wide_kernel[2][3];     // int32 cells, [alg][0 linear gaps, 1 affine, 2 SSE tie-breaks]; nullptr: no such instance
 };
+// int32 cells are the rare path: every mode at 8 rows per lane, the NW variant with linear gaps (the reference's model: long
+// reads whose column-0 border leaves int16) at 16 / 12 as well
+#define VALIGN_STRIP_WIDE_ALL(K)                                                                                       \
+    {{(const void *)&align_strip_wide_kernel<K, kAlgSW>, (const void *)&align_strip_wide_kernel<K, kAlgSW, true>,      \
+      (const void *)&align_strip_wide_kernel<K, kAlgSW, false, true>},                                                 \
+     {(const void *)&align_strip_wide_kernel<K, kAlgNW>, (const void *)&align_strip_wide_kernel<K, kAlgNW, true>,      \
+      (const void *)&align_strip_wide_kernel<K, kAlgNW, false, true>}}
+#define VALIGN_STRIP_WIDE_NW(K) {{nullptr, nullptr, nullptr}, {(const void *)&align_strip_wide_kernel<K, kAlgNW>, nullptr, nullptr}}
+#define VALIGN_STRIP_WIDE_NONE {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}
 #define VALIGN_STRIP_SSE(K) {(const void *)&align_strip_kernel<K, kAlgSW, false, true>, (const void *)&align_strip_kernel<K, kAlgNW, false, true>}
 static const StripGeometry kStripGeometries[] = {
-    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr},
-    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24), nullptr},
+    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}, VALIGN_STRIP_WIDE_NONE},
+    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24), VALIGN_STRIP_WIDE_NONE},
     {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
      {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}, VALIGN_STRIP_SSE(16),
-     (const void *)&align_strip_wide_kernel<16>},
+     VALIGN_STRIP_WIDE_NW(16)},
     {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
      {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}, VALIGN_STRIP_SSE(12),
-     (const void *)&align_strip_wide_kernel<12>},
+     VALIGN_STRIP_WIDE_NW(12)},
     {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
      {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}, VALIGN_STRIP_SSE(8),
-     (const void *)&align_strip_wide_kernel<8>},
+     VALIGN_STRIP_WIDE_ALL(8)},
 };
 #undef VALIGN_STRIP_SSE
+#undef VALIGN_STRIP_WIDE_ALL
+#undef VALIGN_STRIP_WIDE_NW
+#undef VALIGN_STRIP_WIDE_NONE
 
 // Small batches: fill + traceback in one launch, pointer stream in LDS (align_fill_tag_kernel<..., FUSED>)
 struct FusedGeometry {
@@ -95,17 +107,26 @@ bool Engine::align_device(int opt, long long n, const uint8_t *d_reads, const ui
                   short *d_idx, hipStream_t stream, const WalkChain *chain) {
     const int alg = opt & 0xF;
     if (alg > 1 || n <= 0) return false;
-    // NW-variant alignments whose cells leave int16 (the reference's shorts would wrap): int32 cells on the row-strip path,
-    // one pair per register -- linear gaps, default tie-breaks; anything else that leaves the range is refused
+    // Alignments whose cells leave int16 (the reference's shorts would wrap): int32 cells on the row-strip path, one pair per
+    // register (align_strip_wide_kernel) -- every mode; only scores so large that (R + F) * |score| nears 2^28 are refused
     const bool border_bad = alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000);
-    const bool wide_ok = alg == kAlgNW && !sc_.affine && !sse_policy_;
-    if (wide_ok && (border_bad || !int16_range_ok(alg) || wide_align_)) {
+    bool in_range = true;
+    try {
+        check_int16_range(alg);
+    } catch (const std::runtime_error &) {
+        in_range = false;
+    }
+    if (border_bad || !in_range || wide_align_) {
+        const long long worst = std::max({std::abs((long long)sc_.match), std::abs((long long)sc_.mismatch),
+                                          std::abs((long long)(sc_.affine ? sc_.open_read : sc_.gap_read)), std::abs((long long)(sc_.affine ? sc_.open_ref : sc_.gap_ref)),
+                                          sc_.affine ? std::abs((long long)sc_.ext_read) : 0ll, sc_.affine ? std::abs((long long)sc_.ext_ref) : 0ll});
+        if ((long long)(R_ + F_ + 2) * worst >= (1ll << 28))
+            throw std::runtime_error("shape x scoring can leave the int32 range of the DP cells (read_length " + std::to_string(R_) +
+                                     ", ref_length " + std::to_string(F_) + ")");
         hip_check(hipSetDevice(device_), "hipSetDevice");
         align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream, true);
         return false;
     }
-    check_int16_range(alg);
-    if (border_bad) throw std::runtime_error("NW alignment border (read_length * gap score) leaves the int16 range");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (plan_.long_mode) {
         align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
@@ -284,7 +305,7 @@ void Engine::ensure_trace_stream() {
 bool Engine::align_fused(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows, short *d_idx,
                  hipStream_t stream) {
     if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg, 256)) return false;     // (256: the tallest fused geometry)
-    if (wide_align_ && alg == kAlgNW) return false;
+    if (wide_align_) return false;
     try {
         check_int16_range(alg);
     } catch (const std::runtime_error &) {
@@ -343,13 +364,14 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
     const bool affine = sc_.affine;
     if (sse_policy_ && affine)
         throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
+    const int wide_mode = affine ? 1 : (sse_policy_ ? 2 : 0);
     const StripGeometry *geo = nullptr;
     WaveLds lds{};
     for (int budget : {kMaxBlockLds / 2, kMaxBlockLds}) {            // two waves per CU if possible
         for (const StripGeometry &g : kStripGeometries) {
             if (affine && !g.affine_kernel[alg]) continue;
             if (sse_policy_ && !g.sse_kernel[alg]) continue;
-            if (wide && !g.wide_kernel) continue;
+            if (wide && !g.wide_kernel[alg][wide_mode]) continue;
             const WaveLds w = g.lds(64 * g.K, F_);
             if (w.total <= budget && !geo) {
                 geo = &g;
@@ -364,7 +386,8 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
     const int blocks8 = (F_ + 63 + 7) / 8;
     const int row_dwords = ((F_ + 71) / 64 + 2) * 64;
     const size_t strip_words = (size_t)blocks8 * 64 * K * (affine ? 2 : 1);    // per wave (= pair-of-pairs) and strip
-    const int row_sets = (affine || wide) ? 2 : 1;                             // boundary rows: H, and F beside it (affine); one per pair (int32 cells)
+    // boundary row sets: H, and F beside it (affine); int32 cells: those per pair
+    const int row_sets = (affine ? 2 : 1) * (wide ? 2 : 1);
     const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_sets * row_dwords * 4;
     size_t free_b = 0, total_b = 0;
     hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
@@ -403,7 +426,7 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
     hipLaunchKernelGGL(first_invalid_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, d_reads, d_refs, n, R_, F_, d_first_bad_,
                        sse_policy_ ? 1 : 0);
     hip_check(hipGetLastError(), "hipLaunchKernel(first_invalid_kernel)");
-    const void *fn = wide ? geo->wide_kernel : (affine ? geo->affine_kernel[alg] : (sse_policy_ ? geo->sse_kernel[alg] : geo->kernel[alg]));
+    const void *fn = wide ? geo->wide_kernel[alg][wide_mode] : (affine ? geo->affine_kernel[alg] : (sse_policy_ ? geo->sse_kernel[alg] : geo->kernel[alg]));
     if (lds.total > kDefaultBlockLds)
         hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds.total),
                   "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -469,6 +492,7 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
         t.ext_ref = (short)sc_.ext_ref;
         t.strip_rows = rows;
         t.strip_words = (long long)(cnt_waves * strip_words);
+        t.wide_score = wide ? 1 : 0;
         void *targs[] = {&t};
         hip_check(hipLaunchKernel((const void *)&traceback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), targs, 0, stream),
                   "hipLaunchKernel(traceback_kernel)");

@@ -425,103 +425,193 @@ align_strip_kernel(const StripArgs args) {
     }
 }
 
-// ---- int32 cells (round 3): NW-variant alignments whose cells leave int16 ----
-// The reference's shorts wrap where read_length * gap_ref (the NW variant's column-0 border) or a long mismatching stretch
-// goes below -32768 (DefaultKernel.cpp:282-389 computes in short); rounds 1-2 refused such calls.  Same strips, same
-// pointer stream, same traceback -- with ONE pair per register: the wave sweeps the strip twice, pair A then pair B.
-// Pass A stores its 2-bit codes in the low halves of the stream's words, pass B reads them back and adds its high halves
-// (the same lane wrote them: no ordering question).  Boundary rows: one int32 row per pair (StripArgs top / bottom for pair
-// A, top_f / bottom_f for pair B -- the slots the affine kernel uses for F).  Linear gaps, default tie-breaks.
-template <int K>
+// ---- int32 cells: alignments whose cells leave int16 ----
+// The reference's shorts wrap where read_length * gap_ref (the NW variant's column-0 border), a long mismatching stretch
+// or a long, highly scored match leaves [-32768, 32767] (DefaultKernel.cpp:282-389 computes in short); rounds 1-2 refused
+// such calls, round 3 took the NW variant with linear gaps.  Same strips, same pointer stream, same traceback -- with ONE
+// pair per register: the wave sweeps the strip twice, pair A then pair B.  Pass A stores its 2-bit codes in the low
+// halves of the stream's words, pass B reads them back and adds its high halves (the same lane wrote them: no ordering
+// question).  Boundary rows: one int32 row set per pair and per matrix -- set `half` (linear gaps) or 2 * half (H) and
+// 2 * half + 1 (F; affine), one set = the distance StripArgs.top_f - StripArgs.top.  Every mode of align_strip_kernel:
+// both algorithms, linear / affine gaps (the same recurrences and equality-test pointers, plain int32 arithmetic; "minus
+// infinity" is -2^29, the host bounds (R + F) * |score| below 2^28), default / SSE tie-breaks.  The Smith-Waterman end
+// value does not fit EndCell.score: its high half travels in EndCell.pad (TraceArgs.wide_score).
+template <int K, int ALG = kAlgNW, bool AFFINE = false, bool SSE = false>
 __global__ void __launch_bounds__(64)
 align_strip_wide_kernel(const StripArgs args) {
+    static_assert(!(AFFINE && SSE), "the SSE / AVX kernels have linear gaps only");
+    constexpr int W = AFFINE ? 2 * K : K;                 // pointer words per lane and block
     constexpr int G = 64;
+    constexpr int kNinf = -(1 << 29);
+    constexpr int kSets = AFFINE ? 2 : 1;                 // boundary row sets per pair
     using geo = Geo<G, K>;
     const int lane = threadIdx.x;
     const int l = lane;
-    const int R = args.R, F = args.F;
+    const int R = args.R;
     const int pad_total = args.strips * geo::kRows - R;
     const int row0 = args.strip * geo::kRows - pad_total;
     const int strip_pad = args.strip * geo::kRows;
 
     WaveTables w;
-    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, F, args.prof_area, args.refc_stride,
+    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
                                  args.wave_lds, args.match, args.mismatch, w, false, blockIdx.x, 0, row0))
         return;
+    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
     const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
-    const int g_read = args.gap_read, g_ref = args.gap_ref;
-    unsigned *ptr_lane = pointer_stream_lane<G, K, K>(args.ptr, w.pair0, args.blocks8, lane);
+    // Smith-Waterman: magnitudes for the floor-at-zero subtract (as align_strip_kernel); NW variant: signed addends
+    const int g_read = ALG == kAlgSW && !SSE ? -args.gap_read : args.gap_read, g_ref = ALG == kAlgSW && !SSE ? -args.gap_ref : args.gap_ref;
+    const int o_read = ALG == kAlgSW ? -args.open_read : args.open_read, e_read = ALG == kAlgSW ? -args.ext_read : args.ext_read;
+    const int o_ref = ALG == kAlgSW ? -args.open_ref : args.open_ref, e_ref = ALG == kAlgSW ? -args.ext_ref : args.ext_ref;
+    auto gap_add = [](int v, int c) __attribute__((always_inline)) {
+        return (ALG == kAlgSW) ? (int)__builtin_elementwise_sub_sat((unsigned)v, (unsigned)c) : v + c;
+    };
+    constexpr int border_f = (AFFINE && ALG == kAlgNW) ? kNinf : 0;
+    unsigned *ptr_lane = pointer_stream_lane<G, K, W>(args.ptr, w.pair0, args.blocks8, lane);
     const long long pp = w.pair0 / 2;
+    const size_t set_dwords = (size_t)(args.top_f - args.top);
     const bool has_top = args.strip > 0, has_bottom = args.strip + 1 < args.strips;
-    const int steps = args.blocks8 * 8;
+    const int steps = (ALG == kAlgSW) ? ((F + G - 1 + 7) / 8) * 8 : args.blocks8 * 8;
 
     for (int half = 0; half < 2; ++half) {
         const long long pair = w.pair0 + half;
         const long long p_src = w.pair0 + (half > w.last ? w.last : half);
         const int ir = args.first_bad[2 * p_src], jr = args.first_bad[2 * p_src + 1];
-        const unsigned *top = (half ? args.top_f : args.top) + pp * args.row_dwords;
-        unsigned *bottom = (half ? args.bottom_f : args.bottom) + pp * args.row_dwords;
-        // the one row whose arg-max the end-cell rule needs: the last valid read row (DefaultKernel.cpp:307-315, 381-387)
-        const int tracked = ir >= 1 ? ir - 1 + pad_total - strip_pad : -1;          // row of this strip, or outside [0, 64 K)
+        const unsigned *top = args.top + (size_t)(kSets * half) * set_dwords + pp * args.row_dwords;
+        unsigned *bottom = args.bottom + (size_t)(kSets * half) * set_dwords + pp * args.row_dwords;
+        const unsigned *top_f = top + set_dwords;             // (affine only)
+        unsigned *bottom_f = bottom + set_dwords;
+        // NW variant: the one row whose arg-max the end-cell rule needs is the last valid read row
+        // (DefaultKernel.cpp:307-315, 381-387)
+        const int tracked = (ALG == kAlgNW && ir >= 1) ? ir - 1 + pad_total - strip_pad : -1;      // row of this strip, or outside [0, 64 K)
         const int tr_lane = tracked >= 0 ? tracked / K : -1, tr_q = tracked >= 0 ? tracked % K : -1;
+        const uint8_t *read_seq = args.reads + p_src * R;
 
-        int Hl[K];
-        unsigned code[K], acc[K];
-        int row_best = 0, row_col = l;                      // fc semantics of align_strip_kernel: step index of the arg-max
+        int Hl[K], El[AFFINE ? K : 1];
+        unsigned code[K], acc[K], code_g[AFFINE ? K : 1], acc_g[AFFINE ? K : 1];
+        int rb[ALG == kAlgSW ? K : 1], fc[ALG == kAlgSW ? K : 1];      // SW: per-row best and the step of its first occurrence
+        unsigned rinv = 0u;                                             // SSE policy: bit q set where the row's read base is not ACGT
+        int row_best = 0, row_col = l;                      // NW: fc semantics of align_strip_kernel: step index of the arg-max
 #pragma unroll
         for (int q = 0; q < K; ++q) {
             const int pos = row0 + l * K + q;
-            Hl[q] = pos < 0 ? 0 : (pos + 1) * g_ref;      // column 0: a gap of pos + 1 read bases
+            if (SSE) {
+                const int c = (pos >= 0 && pos < R) ? base_class(read_seq[pos]) : 0;
+                rinv |= (c >= 1 && c <= 4) ? 0u : (1u << q);
+            }
+            int border = 0;
+            if (ALG == kAlgNW)                              // column 0: a gap of pos + 1 read bases
+                border = pos < 0 ? 0 : (AFFINE ? args.open_ref + pos * args.ext_ref : (pos + 1) * args.gap_ref);
+            Hl[q] = border;
             code[q] = acc[q] = 0u;
-            if (l == tr_lane && q == tr_q) row_best = Hl[q];
+            if (AFFINE) {
+                El[q] = border_f;
+                code_g[q] = acc_g[q] = 0u;
+            }
+            if (ALG == kAlgSW) {
+                rb[q] = 0;
+                fc[q] = 0;
+            } else if (l == tr_lane && q == tr_q) {
+                row_best = border;
+            }
         }
-        int h_last = Hl[K - 1];
-        int up0 = (l == 0 && row0 - 1 >= 0) ? row0 * g_ref : 0;      // row above the strip at column -1
+        int h_last = Hl[K - 1], f_last = border_f;
+        int up0 = 0;                                        // row above the strip at column -1
+        if (ALG == kAlgNW && l == 0 && row0 - 1 >= 0) up0 = AFFINE ? args.open_ref + (row0 - 1) * args.ext_ref : row0 * args.gap_ref;
         int j = -l;
         unsigned code_addr = lds_offset(w.refc) - 2 * l;
         unsigned top_cur = 0u, top_next = has_top ? top[lane] : 0u;
-        unsigned bot_acc = 0u;
+        unsigned topf_cur = (unsigned)border_f, topf_next = (AFFINE && has_top) ? top_f[lane] : (unsigned)border_f;
+        unsigned bot_acc = 0u, botf_acc = 0u;
 
         for (int t = 0; t < steps; ++t) {
             if ((t & 63) == 0) {
                 top_cur = top_next;
                 top_next = (has_top && t + 64 + lane < args.row_dwords) ? top[t + 64 + lane] : 0u;
+                if (AFFINE) {
+                    topf_cur = topf_next;
+                    topf_next = (has_top && t + 64 + lane < args.row_dwords) ? top_f[t + 64 + lane] : (unsigned)border_f;
+                }
             }
             const int diag0 = up0;
             const int above = __builtin_amdgcn_readlane((int)top_cur, t & 63);
             int from_lane = __builtin_amdgcn_update_dpp(0, h_last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
             asm volatile("" : "+v"(from_lane));
             up0 = l == 0 ? above : from_lane;
+            int fup0 = border_f;
+            if (AFFINE) {
+                const int above_f = __builtin_amdgcn_readlane((int)topf_cur, t & 63);
+                int f_lane = __builtin_amdgcn_update_dpp(0, f_last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                asm volatile("" : "+v"(f_lane));
+                fup0 = l == 0 ? above_f : f_lane;
+            }
             if ((unsigned)j < (unsigned)F) {
                 const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
                 s16x2 S[K];
                 fetch_profile<G, K>(lane_base + ca * geo::kPairStride, lane_base + cb * geo::kPairStride, S);
-                int h = up0, d_prev = diag0;
+                const bool col_inv = SSE && (half ? cb : ca) == (unsigned)geo::kZeroSlab;      // reference base not in ACGT
+                int h = up0, f = fup0, d_prev = diag0;
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     const int d = d_prev + (int)(half ? S[q].y : S[q].x);
-                    const int lg = Hl[q] + g_read, ug = h + g_ref;
                     d_prev = Hl[q];
-                    int m = lg > ug ? lg : ug;
-                    m = d > m ? d : m;
+                    int m;
+                    if constexpr (AFFINE) {
+                        // Gotoh recurrence, pointers by equality tests (align_strip_kernel): H code 0 DIAG / 1 from F / 2 from E
+                        // (DIAG > F > E); gap code bit 1 = E extended, bit 0 = F extended (open preferred on ties)
+                        const int e_open = gap_add(Hl[q], o_read), e_extd = gap_add(El[q], e_read);
+                        const int e = e_extd > e_open ? e_extd : e_open;
+                        El[q] = e;
+                        const int f_open = gap_add(h, o_ref), f_extd = gap_add(f, e_ref);
+                        f = f_extd > f_open ? f_extd : f_open;
+                        m = d > e ? d : e;
+                        m = f > m ? f : m;
+                        code[q] = m == d ? 0u : (m == f ? 1u : 2u);
+                        code_g[q] = (e != e_open ? 2u : 0u) | (f != f_open ? 1u : 0u);
+                    } else if constexpr (SSE) {
+                        // signed gap scores, no zero floor on the gap terms; 3 DIAG (only between two ACGT bases) > 2 LEFT > 1 UP > 0 START
+                        const int lg = Hl[q] + g_read, ug = h + g_ref;
+                        m = lg > ug ? lg : ug;
+                        m = d > m ? d : m;
+                        if (ALG == kAlgSW) m = m > 0 ? m : 0;
+                        const bool diag_ok = m == d && !col_inv && !((rinv >> q) & 1u);
+                        code[q] = diag_ok ? 3u : (m == lg ? 2u : (m == ug ? 1u : 0u));
+                    } else {
+                        const int lg = gap_add(Hl[q], g_read), ug = gap_add(h, g_ref);
+                        m = lg > ug ? lg : ug;
+                        m = d > m ? d : m;
+                        code[q] = m == d ? 0u : (m == ug ? 1u : 2u);          // DIAG > UP > LEFT
+                    }
                     h = m;
                     Hl[q] = m;
-                    code[q] = m == d ? 0u : (m == ug ? 1u : 2u);          // DIAG > UP > LEFT
-                    if (l == tr_lane && q == tr_q && m > row_best) {      // strictly greater: the first arg-max wins
+                    if (ALG == kAlgSW) {
+                        if (m > rb[q]) {                                      // strictly greater: the first arg-max of the row wins
+                            rb[q] = m;
+                            fc[q] = t;
+                        }
+                    } else if (l == tr_lane && q == tr_q && m > row_best) {
                         row_best = m;
                         row_col = t;
                     }
                 }
                 h_last = h;
+                f_last = f;
             }
 #pragma unroll
             for (int q = 0; q < K; ++q) acc[q] = ((acc[q] << 2) | code[q]) & 0xFFFFu;
+            if (AFFINE) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) acc_g[q] = ((acc_g[q] << 2) | code_g[q]) & 0xFFFFu;
+            }
             if ((t & 7) == 7) {
-                unsigned *dst = pointer_stream_block<K>(ptr_lane, t >> 3);
-                unsigned w8[K];
+                unsigned *dst = pointer_stream_block<W>(ptr_lane, t >> 3);
+                unsigned w8[W];
 #pragma unroll
                 for (int q = 0; q < K; ++q) w8[q] = half ? (dst[q] & 0xFFFFu) | (acc[q] << 16) : acc[q];
-                store_block_words<K>(dst, w8);
+                if constexpr (AFFINE) {               // K words of H codes followed by K words of gap codes
+#pragma unroll
+                    for (int q = 0; q < K; ++q) w8[K + q] = half ? (dst[K + q] & 0xFFFFu) | (acc_g[q] << 16) : acc_g[q];
+                }
+                store_block_words<W>(dst, w8);
             }
             if (has_bottom) {
                 const int col = t - (G - 1);
@@ -529,25 +619,73 @@ align_strip_wide_kernel(const StripArgs args) {
                     const int v = __builtin_amdgcn_readlane(h_last, G - 1);
                     bot_acc = lane == (col & 63) ? (unsigned)v : bot_acc;
                     if ((col & 63) == 63 || t == steps - 1) bottom[(col & ~63) + lane] = bot_acc;
+                    if (AFFINE) {
+                        const int vf = __builtin_amdgcn_readlane(f_last, G - 1);
+                        botf_acc = lane == (col & 63) ? (unsigned)vf : botf_acc;
+                        if ((col & 63) == 63 || t == steps - 1) bottom_f[(col & ~63) + lane] = botf_acc;
+                    }
                 }
             }
             ++j;
             code_addr += 2;
         }
 
-        // ---- end cell: the strip that holds the last valid read row writes it (strip 0 when there is none) ----
-        const int i_end = ir - 1;
-        const int owner = i_end >= 0 ? (i_end + pad_total) / geo::kRows : 0;
-        if (owner == args.strip) {
-            int arg_col = 0;
-            if (i_end >= 0) arg_col = __shfl(row_col - l, tr_lane, kWave);
-            const int last_ref = jr - 1;
+        // ---- end cell ----
+        if constexpr (ALG == kAlgSW) {
+            // row-major first maximum (DefaultKernel.cpp:252-256): the largest value, then the smallest row, then the row's
+            // first column; over the strips, a later one only wins with a larger value
+            int bv = 0, bq = 0, bcol = 0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                if (rb[q] > bv) {
+                    bv = rb[q];
+                    bq = q;
+                    bcol = fc[q];
+                }
+            }
+            int vmax = bv;
+#pragma unroll
+            for (int dd = G / 2; dd >= 1; dd >>= 1) {
+                const int other = __shfl_xor(vmax, dd, kWave);
+                vmax = other > vmax ? other : vmax;
+            }
+            int p = bv == vmax ? l * K + bq : 0x7FFFFFFF;
+#pragma unroll
+            for (int dd = G / 2; dd >= 1; dd >>= 1) {
+                const int other = __shfl_xor(p, dd, kWave);
+                p = other < p ? other : p;
+            }
+            const int win_lane = p / K;
+            const int col_t = __shfl(bcol, win_lane, kWave);
             EndCell out;
-            out.pad = 0;
-            out.score = 0;
-            out.read_pos = (short)i_end;
-            out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
-            if (l == 0 && pair < args.n) args.ends[pair] = out;
+            out.score = (short)(vmax & 0xFFFF);
+            out.pad = (short)((unsigned)vmax >> 16);
+            out.read_pos = (short)(strip_pad + p - pad_total);
+            out.ref_pos = (short)(col_t - win_lane);
+            if (vmax <= 0) {
+                out.read_pos = 0;
+                out.ref_pos = 0;
+            }
+            if (l == 0 && pair < args.n) {
+                const EndCell prev = args.ends[pair];
+                const int prev_score = (int)((unsigned)(unsigned short)prev.score | ((unsigned)(unsigned short)prev.pad << 16));
+                if (args.strip == 0 || vmax > prev_score) args.ends[pair] = out;
+            }
+        } else {
+            // the strip that holds the last valid read row writes it (strip 0 when there is none)
+            const int i_end = ir - 1;
+            const int owner = i_end >= 0 ? (i_end + pad_total) / geo::kRows : 0;
+            if (owner == args.strip) {
+                int arg_col = 0;
+                if (i_end >= 0) arg_col = __shfl(row_col - l, tr_lane, kWave);
+                const int last_ref = jr - 1;
+                EndCell out;
+                out.pad = 0;
+                out.score = 0;
+                out.read_pos = (short)i_end;
+                out.ref_pos = (short)(last_ref < arg_col ? last_ref : arg_col);
+                if (l == 0 && pair < args.n) args.ends[pair] = out;
+            }
         }
     }
 }

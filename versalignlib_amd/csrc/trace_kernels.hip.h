@@ -30,7 +30,7 @@ struct EndCell {          // per pair, 8 bytes
     short read_pos;       // 0-based read position of the end cell (-1: empty alignment)
     short ref_pos;        // 0-based ref position (-1: column 0)
     short score;          // SW: value of the end cell; NW: unused
-    short pad;
+    short pad;            // 0 -- or the high half of an int32 end value (align_strip_wide_kernel, TraceArgs.wide_score)
 };
 
 struct FillArgs {
@@ -77,6 +77,7 @@ struct TraceArgs {
     short open_read, ext_read, open_ref, ext_ref;
     int strip_rows;           // > 0: the read was swept in row strips of this many padded rows (strip_kernels.hip.h),
     long long strip_words;    //      each with its own region of the pointer stream, this many dwords apart
+    int wide_score;           // 1: int32 cells -- the end value is EndCell.score (low half) and EndCell.pad (high half)
     int *min_start;           // not null: receives the smallest readStart of the launch (atomicMin; the caller presets R + F) --
                               // the host then copies only the columns from there on out of every row (Engine::align_host)
 };
@@ -99,7 +100,8 @@ __device__ __forceinline__ int trace_walk(const TraceArgs &a, const unsigned *pt
     const int wpb = (a.affine && a.tagged != 2) ? 2 * K : K;      // words per lane and block of steps
     const int half_shift = half * 16;
 
-    int i = e.read_pos, j = e.ref_pos, h = e.score;
+    int i = e.read_pos, j = e.ref_pos;
+    int h = a.wide_score ? (int)((unsigned)(unsigned short)e.score | ((unsigned)(unsigned short)e.pad << 16)) : (int)e.score;
     int k = AL - 2;
     long long cached_at = -1;              // first word index held in c0..c3 (multiple of 4)
     unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
