@@ -214,44 +214,61 @@ score_band_kernel(const BandArgs args) {
     int pre_first = filled, pre_limit = filled;
 
     // this step's and the next step's scores: K int16, rows 2i / 2i + 1 in the halves of dword i
-    unsigned S0[K / 2], S1[K / 2];
+    u32x4 S0[K / 8], S1[K / 8];
 #pragma unroll
-    for (int q = 0; q < K / 2; ++q) S0[q] = S1[q] = 0;
+    for (int q = 0; q < K / 8; ++q) S0[q] = S1[q] = u32x4{0u, 0u, 0u, 0u};
     // LDS address of the lane's scores for the NEXT step (the slab of its next column; carried as an address: a carried
     // byte makes the compiler re-mask it every step)
     unsigned addr_next = lane_prof + zero_slab * kSlabStride;
-    auto load_scores = [&](unsigned addr, unsigned (&S)[K / 2]) __attribute__((always_inline)) {
+    auto load_scores = [&](unsigned addr, u32x4 (&S)[K / 8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < K / 8; ++c) {
-            const u32x4 v = *(lds_cu32x4 *)(addr + c * lay::kChunkBytes);
-            S[4 * c] = v.x; S[4 * c + 1] = v.y; S[4 * c + 2] = v.z; S[4 * c + 3] = v.w;
-        }
+        for (int c = 0; c < K / 8; ++c) S[c] = *(lds_cu32x4 *)(addr + c * lay::kChunkBytes);
     };
     // row q's score out of its register half, sign-extended (folds into the add that uses it)
-    auto score_of = [](const unsigned (&S)[K / 2], int q) __attribute__((always_inline)) -> int {
-        return (q & 1) ? ((int)S[q >> 1] >> 16) : (int)(short)(S[q >> 1] & 0xFFFFu);
+    auto score_of = [](const u32x4 (&S)[K / 8], int q) __attribute__((always_inline)) -> int {
+        const unsigned w = S[q >> 3][(q >> 1) & 3];
+        return (q & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFFu);
     };
 
     // one step: every lane moves one column on.  `S` holds this step's scores, the loads of the next step's go to Snext.
-    auto step = [&](unsigned (&S)[K / 2], unsigned (&Snext)[K / 2]) __attribute__((always_inline)) {
+    auto step = [&](u32x4 (&S)[K / 8], u32x4 (&Snext)[K / 8]) __attribute__((always_inline)) {
         const int diag0 = up0;
-        up0 = up_in;                                                     // the cell above this block's first row
-        const int fup0 = fup_in;                                         // (affine) ... and its F
-        if (!UNIT) {
-            up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));   // ... of the next step (written >= 1 step ago)
-            if (AFFINE) fup_in = (int)*(lds_cu32 *)(pred_ring + ring_f + (rd4 & ring_mask));
+        int fup_cur = 0;
+        if (!(UNIT && K == 16)) {
+            up0 = up_in;                                                 // the cell above this block's first row
+            fup_cur = fup_in;                                            // (affine) ... and its F
+            if (!UNIT) {
+                up_in = (int)*(lds_cu32 *)(pred_ring + (rd4 & ring_mask));   // ... of the next step (written >= 1 step ago)
+                if (AFFINE) fup_in = (int)*(lds_cu32 *)(pred_ring + ring_f + (rd4 & ring_mask));
+            }
         }
-        load_scores(addr_next, Snext);                                   // step t + 1
-        // (inline assembly: through the compiler the byte comes back as an "any-extended" load and is masked again every
-        // step; ds_read_u8 zero-extends.  The compiler does not count this load -- LDS returns in order, its own waits only
-        // become more conservative -- so the wait sits with the one use, at the end of the step.)
+        // (inline assembly: through the compiler the code byte comes back as an "any-extended" load and is masked again
+        // every step; ds_read_u8 zero-extends.  The compiler does not count these loads -- LDS returns in order, its own
+        // waits only become more conservative -- so the wait sits with the one use, at the end of the step.)
         unsigned code;
-        asm volatile("ds_read_u8 %0, %1" : "=v"(code) : "v"(ca));        // step t + 2
+        if constexpr (UNIT && K == 16) {
+            // every LDS operation of the step in one place, so that the count behind the hand-over's ds_swizzle (issued at
+            // the end of the previous step, see below) is known: two score loads and the code byte later, it has landed
+            // (the loads land in the registers the next step reads: no copy of a register in flight)
+            if constexpr (AFFINE)
+                asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_u8 %2, %6\n\ts_waitcnt lgkmcnt(3)"
+                             : "=&v"(Snext[0]), "=&v"(Snext[1]), "=&v"(code), "+v"(up_in), "+v"(fup_in)
+                             : "v"(addr_next), "v"(ca), "n"(lay::kChunkBytes));
+            else
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_u8 %2, %5\n\ts_waitcnt lgkmcnt(3)"
+                             : "=&v"(Snext[0]), "=&v"(Snext[1]), "=&v"(code), "+v"(up_in)
+                             : "v"(addr_next), "v"(ca), "n"(lay::kChunkBytes));
+            up0 = up_in;                                                 // (only now: the registers were in flight)
+            fup_cur = fup_in;
+        } else {
+            load_scores(addr_next, Snext);                               // step t + 1
+            asm volatile("ds_read_u8 %0, %1" : "=v"(code) : "v"(ca));    // step t + 2
+        }
         ca = ((ca + 1u) & code_mask) | codes_lds;
         int h_out = 0, f_out = 0;
         if (AFFINE) {
             if ((unsigned)u <= (unsigned)span) {
-                int f = fup0;
+                int f = fup_cur;
                 int ho = (int)__builtin_elementwise_sub_sat((unsigned)up0, omag_ref);          // H - open of the row above
                 int d_cur = diag0 + score_of(S, 0), d_prev = 0, h = 0;
 #pragma unroll
@@ -309,27 +326,37 @@ score_band_kernel(const BandArgs args) {
             }
             h_out = h;
         }
-        if (UNIT) {
-            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window); the two groups' rings
-            // close through two scalar registers: lane 0 <- lane 31, lane 32 <- lane 63
-            const int s31 = __builtin_amdgcn_readlane(h_out, 31), s63 = __builtin_amdgcn_readlane(h_out, 63);
-            int v = __builtin_amdgcn_update_dpp(h_out, h_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-            asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32" : "+v"(v) : "s"(s31), "s"(s63));
-            up_in = v;
-            if (AFFINE) {
-                const int f31 = __builtin_amdgcn_readlane(f_out, 31), f63 = __builtin_amdgcn_readlane(f_out, 63);
-                int vf = __builtin_amdgcn_update_dpp(f_out, f_out, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-                asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32" : "+v"(vf) : "s"(f31), "s"(f63));
-                fup_in = vf;
-            }
-        } else {
+        if (!UNIT) {
             *(__attribute__((address_space(3))) unsigned *)(my_ring + (t4 & ring_mask)) = (unsigned)h_out;
             if (AFFINE) *(__attribute__((address_space(3))) unsigned *)(my_ring + ring_f + (t4 & ring_mask)) = (unsigned)f_out;
             rd4 += 256;
             t4 += 256;
         }
         static_assert(kSlabStride == 512, "the shift below");
+        if constexpr (UNIT && K == 16) {
+            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window), lanes 0 and 32 take
+            // lanes 31 and 63: the rotation of each half of the wave by one lane is ONE ds_swizzle (rotate mode, no LDS
+            // memory, no VALU slot -- the DPP shift with its two readlane / writelane fix-ups was 5 VALU instructions a
+            // step), issued BEHIND the step's wait: its latency passes under the next step's loads and the other waves
+            if constexpr (AFFINE)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %0, %3, 9, %4\n\t"
+                             "ds_swizzle_b32 %1, %5 offset:swizzle(ROTATE,1,1)\n\tds_swizzle_b32 %2, %6 offset:swizzle(ROTATE,1,1)"
+                             : "=&v"(addr_next), "=&v"(up_in), "=&v"(fup_in) : "v"(code), "v"(lane_prof), "v"(h_out), "v"(f_out));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %0, %2, 9, %3\n\tds_swizzle_b32 %1, %4 offset:swizzle(ROTATE,1,1)"
+                             : "=&v"(addr_next), "=&v"(up_in) : "v"(code), "v"(lane_prof), "v"(h_out));
+            ++u;
+            return;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshl_add_u32 %0, %1, 9, %2" : "=v"(addr_next) : "v"(code), "v"(lane_prof));
+        if (UNIT) {
+            // lane l's next cell from above is what lane l - 1 just computed (0 outside its window), lanes 0 and 32 take
+            // lanes 31 and 63: the rotation of each half of the wave by one lane is ONE ds_swizzle (rotate mode, no LDS
+            // memory, no VALU slot -- the DPP shift with its two readlane / writelane fix-ups was 5 VALU instructions a
+            // step); issued behind the step's wait, its latency passes under the other waves of the SIMD
+            up_in = __builtin_amdgcn_ds_swizzle(h_out, 0xC420 /* swizzle(ROTATE, 1, 1): lane i <- lane i - 1 within 32 */);
+            if (AFFINE) fup_in = __builtin_amdgcn_ds_swizzle(f_out, 0xC420);
+        }
         ++u;
     };
 
