@@ -94,6 +94,17 @@ struct BandLds {
 // move / a second delay ring).  All values floored at 0 by the saturating subtracts, which for Smith-Waterman is the
 // recurrence itself (a gap score below zero never beats the floor).  SYM then means open_read == open_ref and ext_read ==
 // ext_ref: H - open is computed once per cell and serves E of the next column and F of the next row.
+// 3-bit class codes for the letters 'A' + t (t = 0..19): A 0, T 1, C 2, G 3 -- the class order of the profile's slabs -- every
+// other letter and entry 20 (what all other bytes clamp to): 4
+constexpr unsigned long long band_class_table() {
+    unsigned long long table = 0;
+    for (int t = 0; t <= 20; ++t) {
+        const unsigned long long c = t == 0 ? 0 : (t == 19 ? 1 : (t == 2 ? 2 : (t == 6 ? 3 : 4)));
+        table |= c << (3 * t);
+    }
+    return table;
+}
+
 template <int K, bool SYM, bool UNIT, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
 score_band_kernel(const BandArgs args) {
@@ -167,7 +178,6 @@ score_band_kernel(const BandArgs args) {
     // of group 1 -- 64 lanes x 2 = 16 rows x 4 classes x 2 groups.
     static_assert(K == 16, "the cooperative profile rewrite below maps 64 lanes onto 16 rows x 4 classes");
     const int my_q = (lane >> 2) & (K - 1), my_c = lane & 3;
-    const unsigned my_letter = (0x47435441u >> (8 * my_c)) & 0xFFu;          // 'A', 'T', 'C', 'G': classes 0..3
     const int pg0 = (half > last) ? last : half, pg1 = (2 + half > last) ? last : 2 + half;
     const uint8_t *rows0 = args.reads + (pair0 + pg0) * R - args.pad_rows + my_q;     // + b * K: row my_q of block b
     const uint8_t *rows1 = args.reads + (pair0 + pg1) * R - args.pad_rows + my_q;
@@ -176,11 +186,19 @@ score_band_kernel(const BandArgs args) {
         const int at = b * K;
         return (b < args.nb && (unsigned)(at - row_first) < (unsigned)R) ? (unsigned)rows[at] : 0u;
     };
+    // class of a base without a branch: 0..3 for A / T / C / G in either case, 4 for anything else -- 3-bit entries for the
+    // letters 'A' + t, t = 0..19, in one 64-bit constant; every other byte clamps to entry 20 (bytes >= 0x80 keep bit 7 under
+    // the case fold and bytes below 'A' wrap: both land far beyond 20)
+    constexpr unsigned long long kClassTable = band_class_table();
+    auto class_of = [](unsigned ch) __attribute__((always_inline)) -> unsigned {
+        unsigned t = (ch & 0xDFu) - 'A';
+        t = t < 20u ? t : 20u;
+        return (unsigned)(kClassTable >> (3u * t)) & 7u;
+    };
     // substitution score of a read base against this lane's class: 0 unless both are one of ACGT
     auto entry_score = [&](unsigned ch) __attribute__((always_inline)) -> int {
-        const unsigned u = ch & 0xDFu, t = u - 'A';                              // bytes >= 0x80 keep bit 7: never a letter
-        const bool valid = t < 20u && ((0x80045u >> t) & 1u);                    // A, C, G, T
-        return u == my_letter ? (int)args.match : (valid ? (int)args.mismatch : 0);
+        const unsigned c = class_of(ch);
+        return c == (unsigned)my_c ? (int)args.match : (c < 4u ? (int)args.mismatch : 0);
     };
     // reference bases for the ring: lane -> column first + lane % 32 (+ 32 in the second round) of its group's pair;
     // the ring holds the slab of the lane-independent part of the profile address: class * groups + group, or the zero slab
@@ -189,12 +207,11 @@ score_band_kernel(const BandArgs args) {
         return first + l < F ? (unsigned)refl[first] : 0u;
     };
     auto slab_of = [&](unsigned ch) __attribute__((always_inline)) -> unsigned {
-        const unsigned u = ch & 0xDFu, t = u - 'A';
-        const bool valid = t < 20u && ((0x80045u >> t) & 1u);
-        // A (t = 0) -> 0, T (19) -> 1, C (2) -> 2, G (6) -> 3
-        const unsigned cls = t == 0u ? 0u : (t == 19u ? 1u : (t == 2u ? 2u : 3u));
-        return valid ? cls * kBandGroups + (unsigned)grp : zero_slab;
+        const unsigned slab = class_of(ch) * kBandGroups + (unsigned)grp;     // class 4 -> 8 or 9: the zero slab
+        return slab < zero_slab ? slab : zero_slab;
     };
+    // (a round none of whose lanes has a column to commit is skipped as a whole: the second one at every event that brings at
+    // most 32 new columns -- all events of a square matrix)
     auto commit_codes = [&](int first, int limit, unsigned b0, unsigned b1) __attribute__((always_inline)) {
         const int c0 = first + l, c1 = first + kBandG + l;
         if (c0 < limit) codes[grp * args.code_cols + (c0 & code_mask)] = (unsigned char)slab_of(b0);
