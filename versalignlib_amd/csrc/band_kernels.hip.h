@@ -159,9 +159,17 @@ score_band_kernel(const BandArgs args) {
 
     // per row: H of the previous column; linear gaps: max(H - g, 0) beside it (shared-gap form); affine: E of the previous
     // column and, with symmetric scores, max(H - open, 0)
-    int Hl[K], Gl[K], El[AFFINE ? K : 1];
+    // H of the lane's K rows at its current column and, beside it in a 64-bit register pair, G = H - gap (shared gap score:
+    // what both neighbours subtract) -- pairs so that the event's reset of a lane is K 64-bit moves instead of 2 K
+    typedef unsigned long long u64;
+    u64 HG[K];
+    int El[AFFINE ? K : 1];
+    auto h_of = [&](int q) __attribute__((always_inline)) -> int { return (int)(unsigned)HG[q]; };
+    auto g_of = [&](int q) __attribute__((always_inline)) -> int { return (int)(unsigned)(HG[q] >> 32); };
+    auto put_hg = [&](int q, int h, int g) __attribute__((always_inline)) { HG[q] = ((u64)(unsigned)g << 32) | (u64)(unsigned)h; };
+    auto put_h = [&](int q, int h) __attribute__((always_inline)) { HG[q] = (HG[q] & 0xFFFFFFFF00000000ull) | (u64)(unsigned)h; };
 #pragma unroll
-    for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+    for (int q = 0; q < K; ++q) HG[q] = 0;
 #pragma unroll
     for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = 0;
     int up0 = 0, up_in = 0, best = 0;      // up_in: the predecessor's cell for the coming step (read one step ahead)
@@ -291,9 +299,9 @@ score_band_kernel(const BandArgs args) {
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     int d_next = 0;
-                    if (q + 1 < K) d_next = Hl[q] + score_of(S, q + 1);  // before Hl[q] is overwritten
+                    if (q + 1 < K) d_next = h_of(q) + score_of(S, q + 1);  // before H of the row is overwritten
                     const int ex = (int)__builtin_elementwise_sub_sat((unsigned)El[q], emag_read);
-                    const int eo = SYM ? Gl[q] : (int)__builtin_elementwise_sub_sat((unsigned)Hl[q], omag_read);
+                    const int eo = SYM ? g_of(q) : (int)__builtin_elementwise_sub_sat((unsigned)h_of(q), omag_read);
                     const int e = ex > eo ? ex : eo;
                     const int fx = (int)__builtin_elementwise_sub_sat((unsigned)f, emag_ref);
                     f = fx > ho ? fx : ho;
@@ -301,9 +309,8 @@ score_band_kernel(const BandArgs args) {
                     m = m > f ? m : f;
                     h = m;
                     El[q] = e;
-                    Hl[q] = m;
                     ho = (int)__builtin_elementwise_sub_sat((unsigned)m, omag_ref);
-                    if (SYM) Gl[q] = ho;
+                    if (SYM) put_hg(q, m, ho); else put_h(q, m);
                     if (q & 1) {
                         int b2 = best > d_prev ? best : d_prev;
                         best = b2 > d_cur ? b2 : d_cur;
@@ -323,15 +330,14 @@ score_band_kernel(const BandArgs args) {
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 int d_next = 0;
-                if (q + 1 < K) d_next = Hl[q] + score_of(S, q + 1);      // before Hl[q] is overwritten
-                int left_c = Gl[q];
-                if (!SYM) left_c = (int)__builtin_elementwise_sub_sat((unsigned)Hl[q], gmag_read);
+                if (q + 1 < K) d_next = h_of(q) + score_of(S, q + 1);    // before H of the row is overwritten
+                int left_c = g_of(q);
+                if (!SYM) left_c = (int)__builtin_elementwise_sub_sat((unsigned)h_of(q), gmag_read);
                 int m = d_cur > left_c ? d_cur : left_c;
                 m = m > up_c ? m : up_c;
                 h = m;
-                Hl[q] = m;
                 up_c = (int)__builtin_elementwise_sub_sat((unsigned)m, gmag_ref);
-                if (SYM) Gl[q] = up_c;
+                if (SYM) put_hg(q, m, up_c); else put_h(q, m);
                 if (q & 1) {
                     int b2 = best > d_prev ? best : d_prev;
                     best = b2 > d_cur ? b2 : d_cur;
@@ -388,7 +394,7 @@ score_band_kernel(const BandArgs args) {
         filled = pre_limit > filled ? pre_limit : filled;
         if (l == ls) {
 #pragma unroll
-            for (int q = 0; q < K; ++q) Hl[q] = Gl[q] = 0;
+            for (int q = 0; q < K; ++q) HG[q] = 0;
 #pragma unroll
             for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = 0;
             up0 = 0;
