@@ -226,14 +226,24 @@ score_long_kernel(const LongArgs args) {
             constexpr int TRACK = decltype(track_tag)::value;
             const cell_t diag0 = up0;
             // row above: previous lane of the group; for the first lane the previous strip's bottom row
-            const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
+            // (one instruction: the shift writes every lane that has a lane before it -- G = 64: all but lane 0, which keeps
+            // the "old" operand, the ring's value; narrower groups select)
             const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
-            up0 = ops::from_bits(l == 0 ? from_ring : from_lane);
+            if constexpr (G == kWave) {
+                up0 = ops::from_bits((unsigned)__builtin_amdgcn_update_dpp((int)from_ring, (int)ops::bits(h_last), 0x138, 0xF, 0xF, false));
+            } else {
+                const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
+                up0 = ops::from_bits(l == 0 ? from_ring : from_lane);
+            }
             cell_t fup0 = border_f;
             if constexpr (AFFINE) {
-                const unsigned f_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(f_last), 0x138, 0xF, 0xF, true);
                 const unsigned f_ring = *(lds_cu32 *)(in_base_f + (((c_lo + t) & (kRing - 1)) << 2));
-                fup0 = ops::from_bits(l == 0 ? f_ring : f_lane);
+                if constexpr (G == kWave) {
+                    fup0 = ops::from_bits((unsigned)__builtin_amdgcn_update_dpp((int)f_ring, (int)ops::bits(f_last), 0x138, 0xF, 0xF, false));
+                } else {
+                    const unsigned f_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(f_last), 0x138, 0xF, 0xF, true);
+                    fup0 = ops::from_bits(l == 0 ? f_ring : f_lane);
+                }
             }
             // LDS fetches run ahead of the arithmetic (every lane, every step): the raw profile dwords of
             // this step are in registers, the rows of step t+1 and the slab numbers of step t+2 are
