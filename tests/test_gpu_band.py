@@ -52,6 +52,35 @@ def test_block_chain_matches_the_block_band(R, F, n, band, seed):
             assert (got <= cpu_ref.score(0, reads, refs, sc, threads=8)).all()
 
 
+def test_block_chain_classifies_every_byte_value():
+    """All 256 byte values in reads and references (the chain's event code takes base classes out of a 64-bit table constant:
+    letters 'A' + t for t < 20, everything else -- control bytes, punctuation, bytes >= 0x80, the letters' neighbours -- is no
+    base).  Each pair carries 32 consecutive byte values at the same read / reference offsets, upper and lower case bases
+    around them; against the oracle on the chain's blocks, linear and affine gaps."""
+    R, F, n, band = 640, 700, 8, 64
+    reads, refs = synth.make_pairs(n, R, F, seed=71, sub_rate=0.05, n_run_frac=0.0, short_frac=0.0)
+    refs[:, :R] = reads                                   # the diagonal is inside the band
+    rng = np.random.default_rng(72)
+    for p in range(n):
+        low = rng.choice(R - 1, size=40, replace=False)
+        reads[p, low] |= 0x20                              # some lower-case bases
+        vals = np.arange(32 * p, 32 * p + 32, dtype=np.uint8)
+        at = rng.choice(R - 1, size=32, replace=False)
+        reads[p, at] = vals
+        refs[p, at[::2]] = vals[::2]                       # half of them face the same byte, half a base
+    seen = set(np.unique(reads).tolist())
+    assert seen.issuperset(range(256))
+    for aff in (None, (-5, -1, -5, -1)):
+        sc = cpu_ref.Scoring.make(2, -1, -3, -3, *(aff or ()))
+        eng = hipkernel.Engine(R, F, hipkernel.Scoring.make(2, -1, -3, -3, **(dict(zip(("open_read", "ext_read", "open_ref", "ext_ref"), aff)) if aff else {})))
+        eng.set_band_width(band)
+        assert eng.describe(0, n)["band_block_rows"] == 16
+        got = eng.score_host(0, reads, refs, threads=2)
+        eng.close()
+        exp = cpu_ref.score_banded_sw(reads, refs, band, sc, threads=4, block_rows=16, col_align=1, affine=aff is not None)
+        assert np.array_equal(got, exp), (aff, got, exp)
+
+
 def test_block_chain_against_the_strip_kernel(monkeypatch):
     """The two kernels compute two documented supersets of the per-cell band: blocks of 16 rows (the chain) inside
     blocks of 160 rows with columns aligned to 4 (the strips).  Each equals the oracle's statement of its own blocks."""
