@@ -107,6 +107,14 @@ __device__ __forceinline__ unsigned from_prev_lane(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
+// value of the previous lane of the lane's G-lane group, 0 in the group's first lane.  Groups of 16 are the DPP rows:
+// row_shr:1 with bound_ctrl is exactly that in ONE instruction (else: wave-wide shift, then the mask)
+template <int G>
+__device__ __forceinline__ unsigned group_prev_or_zero(unsigned v, unsigned lmask) {
+    if (G == 16) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    return from_prev_lane(v) & lmask;
+}
+
 // base class of one input byte: A/a 1, T/t 2, C/c 3, G/g 4, N/n 5, else 0
 __device__ __forceinline__ int base_class(unsigned ch) {
     const unsigned u = ch & 0xDFu;            // fold case; bytes >= 0x80 never match
@@ -553,6 +561,7 @@ score_kernel(const ScoreArgs args) {
         HOl[q] = (ALG == kAlgSW) ? pk(0) : (F16 ? cell_add(Hl[q], pk(__builtin_bit_cast(short, open_h))) : Hl[q] + o_ref);
     }
     s16x2 up0 = pk(0), h_last = Hl[K - 1], f_last = border_f, best = pk(0);
+    s16x2 fup_keep = border_f;       // NW variant, 16-lane groups: F of the row above the lane's rows (see the step)
     // NW result: max(0, last row, last column) -- kept as "value - centre" (half floats: the sum itself may not be exact)
     s16x2 row_best = cell(-rcentre);
     int j = -l;                                                  // this lane's column at step t
@@ -604,11 +613,19 @@ score_kernel(const ScoreArgs args) {
         if (TILT) up0 = as_pk(as_u32(up0) | as_u32(top_row));         // (zero in every lane but the group leader)
         s16x2 fup0 = border_f;
         if (AFFINE) {
-            const unsigned fv = from_prev_lane(as_u32(f_last));
-            fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+            if (G == 16 && ALG == kAlgSW) {      // (row_shr:1: the group's first lane reads 0, the Smith-Waterman border)
+                fup0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(f_last), 0x111, 0xF, 0xF, true));
+            } else if (G != 16) {
+                const unsigned fv = from_prev_lane(as_u32(f_last));
+                fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+            }
+            if (G == 16 && ALG == kAlgNW) {      // the group's first lane keeps what the register held: the border, for good
+                fup_keep = as_pk((unsigned)__builtin_amdgcn_update_dpp((int)as_u32(fup_keep), (int)as_u32(f_last), 0x111, 0xF, 0xF, false));
+                fup0 = fup_keep;
+            }
         }
         s16x2 gup0 = pk(0);        // kGapSymF16 (SW): max(h + g, 0) of the row above
-        if (LINF16_SW) gup0 = as_pk(from_prev_lane(as_u32(f_last)) & lmask);
+        if (LINF16_SW) gup0 = as_pk(group_prev_or_zero<G>(as_u32(f_last), lmask));
         if (PIPE) {
             merge_profile<K>(pa, pb, S);                                     // step t's scores
             lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);     // step t+1's profile rows

@@ -502,7 +502,7 @@ align_fill_kernel(const FillArgs args) {
         if (G == 16) {
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
         } else {
-            up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+            up0 = as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask));
         }
         if (!MASKED || (unsigned)j < (unsigned)F) {
             const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
@@ -795,7 +795,7 @@ align_fill_tag_kernel(const FillArgs args) {
         if (G == 16) {
             up0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(h_last), 0x111, 0xF, 0xF, true));
         } else {
-            up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+            up0 = as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask));
         }
         if (TILT) up0 = as_pk(as_u32(up0) | as_u32(top_row));         // (zero in every lane but the group leader)
         s16x2 S[K];
@@ -1041,6 +1041,7 @@ align_fill_affine_kernel(const FillArgs args) {
         fc[0] = pk((short)l);
     }
     s16x2 h_last = Hl[K - 1], f_last = border_f;
+    s16x2 fup_keep = border_f;       // NW variant, 16-lane groups: F of the row above the lane's rows (see the step)
     s16x2 up0 = pk(0);
     int j = -l;
 
@@ -1062,9 +1063,17 @@ align_fill_affine_kernel(const FillArgs args) {
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
-        const unsigned fv = from_prev_lane(as_u32(f_last));
-        const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        up0 = as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask));
+        s16x2 fup0;
+        if (G == 16 && ALG == kAlgSW) {          // (row_shr:1: the group's first lane reads 0, the Smith-Waterman border)
+            fup0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(f_last), 0x111, 0xF, 0xF, true));
+        } else if (G == 16) {                    // NW: the group's first lane keeps what the register held -- the border, for good
+            fup_keep = as_pk((unsigned)__builtin_amdgcn_update_dpp((int)as_u32(fup_keep), (int)as_u32(f_last), 0x111, 0xF, 0xF, false));
+            fup0 = fup_keep;
+        } else {
+            const unsigned fv = from_prev_lane(as_u32(f_last));
+            fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        }
         s16x2 S[K];
         merge_profile<K>(pa, pb, S);
         lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
@@ -1258,6 +1267,7 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         fc[0] = pk((short)l);
     }
     s16x2 h_last = Hl[K - 1], f_last = border_f;
+    s16x2 fup_keep = border_f;       // NW variant, 16-lane groups: F of the row above the lane's rows (see the step)
     s16x2 up0 = pk(0);
     int j = -l;
     // tilted frame: the all-zero row above padded row 0 reads -ext_ref * (-1) - ext_read * j in lane 0 of a group,
@@ -1291,10 +1301,18 @@ align_fill_affine_tag_kernel(const FillArgs args) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool LAST_ONLY = decltype(last_only_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = TILT ? as_pk((from_prev_lane(as_u32(h_last)) & lmask) | as_u32(top_row))
-                   : as_pk(from_prev_lane(as_u32(h_last)) & lmask);
-        const unsigned fv = from_prev_lane(as_u32(f_last));
-        const s16x2 fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        up0 = TILT ? as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask) | as_u32(top_row))
+                   : as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask));
+        s16x2 fup0;
+        if (G == 16 && ALG == kAlgSW) {          // (row_shr:1: the group's first lane reads 0, the Smith-Waterman border)
+            fup0 = as_pk((unsigned)__builtin_amdgcn_update_dpp(0, (int)as_u32(f_last), 0x111, 0xF, 0xF, true));
+        } else if (G == 16) {                    // NW: the group's first lane keeps what the register held -- the border, for good
+            fup_keep = as_pk((unsigned)__builtin_amdgcn_update_dpp((int)as_u32(fup_keep), (int)as_u32(f_last), 0x111, 0xF, 0xF, false));
+            fup0 = fup_keep;
+        } else {
+            const unsigned fv = from_prev_lane(as_u32(f_last));
+            fup0 = (ALG == kAlgNW) ? as_pk(l == 0 ? as_u32(border_f) : fv) : as_pk(fv & lmask);
+        }
         s16x2 S[K];
         merge_profile<K>(pa, pb, S);
         lds_load_lane<K>(lane_base + ca_next * geo::kPairStride, pa);
@@ -1481,7 +1499,7 @@ align_fill_sse_kernel(const FillArgs args) {
     auto step = [&](auto masked_tag, int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const s16x2 diag0 = up0;
-        up0 = as_pk(from_prev_lane(as_u32(h_last)) & lmask);
+        up0 = as_pk(group_prev_or_zero<G>(as_u32(h_last), lmask));
         if (!MASKED || (unsigned)j < (unsigned)F) {
             const unsigned ca = *(lds_cu8 *)(code_addr), cb = *(lds_cu8 *)(code_addr + 1);
             s16x2 S[K];
