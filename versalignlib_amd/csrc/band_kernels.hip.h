@@ -104,6 +104,10 @@ constexpr unsigned long long band_class_table() {
     }
     return table;
 }
+static_assert(((band_class_table() >> (3 * ('A' - 'A'))) & 7) == 0 && ((band_class_table() >> (3 * ('T' - 'A'))) & 7) == 1 &&
+                  ((band_class_table() >> (3 * ('C' - 'A'))) & 7) == 2 && ((band_class_table() >> (3 * ('G' - 'A'))) & 7) == 3 &&
+                  ((band_class_table() >> (3 * ('N' - 'A'))) & 7) == 4 && ((band_class_table() >> (3 * 20)) & 7) == 4,
+              "classes of the profile's slabs: A, T, C, G; N and everything else: none");
 
 template <int K, bool SYM, bool UNIT, bool AFFINE = false>
 __global__ void __launch_bounds__(64)
