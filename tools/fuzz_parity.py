@@ -21,9 +21,11 @@ from oracle import cpu_ref                                          # noqa: E402
 from versalignlib_amd import build, host, synth                    # noqa: E402
 
 
-def draw_case(rng):
-    kind = rng.choice(["short", "short", "short", "mid", "long", "tiny"])
-    if kind == "tiny":
+def draw_case(rng, big=False):
+    kind = "big" if big else rng.choice(["short", "short", "short", "mid", "long", "tiny"])
+    if kind == "big":                                     # many pairs: the chunked host pipeline, tail chunks, every slot
+        R, F = int(rng.integers(30, 200)), int(rng.integers(60, 600))
+    elif kind == "tiny":
         R, F = int(rng.integers(1, 20)), int(rng.integers(1, 30))
     elif kind == "short":
         R, F = int(rng.integers(8, 400)), int(rng.integers(8, 900))
@@ -33,6 +35,8 @@ def draw_case(rng):
         R, F = int(rng.integers(2049, 5000)), int(rng.integers(100, 5000))
     cells = R * F
     n = int(max(1, min(rng.integers(1, 400), 6_000_000 // max(cells, 1))))
+    if kind == "big":
+        n = int(rng.integers(40_000, 300_000))
     match = int(rng.integers(1, 6))
     mismatch = -int(rng.integers(0, 7))
     affine = bool(rng.random() < 0.45)
@@ -103,7 +107,7 @@ def run_case(c, verbose=False):
             if not np.array_equal(got, exp):
                 bad = np.nonzero(got != exp)[0]
                 return "score opt %d: %d of %d differ, first %s got %s exp %s" % (opt, bad.size, n, bad[:4], got[bad[:4]], exp[bad[:4]])
-        if R * F * n <= 40_000_000:                       # (the oracle keeps a pointer matrix per thread)
+        if R * F * n <= 40_000_000 or (n >= 40_000 and R * F * n <= 12_000_000_000):     # (the oracle keeps a pointer matrix per thread)
             for opt in (host.SW, host.NW):
                 try:
                     rows, idx = hip.compute_alignments(opt, reads, refs, normalise=False)
@@ -125,13 +129,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--big-every", type=int, default=0, help="every K-th case has 40k-300k pairs (0: none)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     i = 0
     done = 0
     while time.time() - t0 < a.seconds or (a.only >= 0 and i <= a.only):
-        c = draw_case(rng)
+        c = draw_case(rng, big=a.big_every > 0 and i % a.big_every == a.big_every - 1)
         if a.only < 0 or i == a.only:
             try:
                 err = run_case(c)
