@@ -174,6 +174,44 @@ def test_bench_on_two_real_gpus():
     assert line["verified"]["mismatches"] == 0 and line["verified"]["pairs"] > 0
 
 
+_RCCL_REHEARSAL = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VALIGN_ROOT"])
+from versalignlib_amd import shard
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)                 # as bench.py: RCCL, one rank per GPU
+gloo = dist.new_group(backend="gloo")
+local = (torch.arange(100003, device=dev) % 30011 - 15000).to(torch.int16)
+send = local.contiguous().view(torch.uint8)                     # scores travel as bytes: RCCL has no int16
+recv = torch.empty(send.numel() * dist.get_world_size(), dtype=torch.uint8, device=dev)
+dist.all_gather_into_tensor(recv, send)
+assert torch.equal(recv.view(torch.int16), local)
+assert torch.equal(shard.all_gather_scores(local, n_total=local.numel()), local)
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+s = local.to(torch.int64).sum().reshape(1)
+dist.all_reduce(s)
+assert float(t.item()) == 1.25 and int(s.item()) == int(local.to(torch.int64).sum().item())
+dist.barrier()
+torch.cuda.synchronize()
+dist.barrier(group=gloo)
+dist.destroy_process_group()
+print("RCCL_REHEARSAL_OK")
+"""
+
+
+def test_torch_distributed_rccl_calls_of_the_bench_on_one_rank():
+    """bench.py's N > 1 path has never met a second GPU (the driver's 8-GPU node is the first): what CAN run on one device is
+    every torch.distributed call it makes -- process group on the `nccl` backend (= RCCL) bound to the device, a gloo group
+    beside it, the byte-view all-gather of int16 scores, the MAX / SUM all-reduces, the barriers -- with a world of one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", VALIGN_ROOT=ROOT)
+    proc = subprocess.run([sys.executable, "-c", _RCCL_REHEARSAL], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=600)
+    assert proc.returncode == 0 and "RCCL_REHEARSAL_OK" in proc.stdout, (proc.stdout[-1000:], proc.stderr[-3000:])
+
+
 def test_in_plugin_rccl_all_gather_of_shard_scores():
     """hip_devices_allgather = 1: every shard's scores stay on its device, an RCCL all-gather (librccl.so loaded by the
     plugin, one communicator per device in this one process) assembles the vector on every device and the host copy
