@@ -469,6 +469,35 @@ def test_alignments_whose_cells_leave_int16_every_mode(mode, alg):
         _same_alignments(got, cpu_ref.align(alg, reads, refs, sc1, threads=8, **okw), ("scores / scale on int16", mode, alg, R, F))
 
 
+@pytest.mark.parametrize("k", [8, 12, 16])
+@pytest.mark.parametrize("mode", ["linear", "affine", "sse"])
+def test_strip_alignment_kernels_at_every_strip_height(monkeypatch, k, mode):
+    """The row-strip alignment kernels exist at 16, 12 and 8 rows per lane (the engine takes the height that pads the read
+    least; VALIGN_HIP_DEBUG strip_k forces one): each against the oracle on a shape of several strips whose reference is
+    longer than the ring of slab numbers (128 columns, refilled 64 at a time) many times over, and on one whose reference is
+    shorter than the ring."""
+    debug_switches(monkeypatch, strip_k=k)
+    keys, sc, okw = _wide_case(mode, 1)
+    for R, F, n, seed in ((2300, 1700, 7, 201), (2100, 90, 9, 202)):
+        reads, refs = synth.make_pairs(n, R, F, seed=seed, indel_rate=0.02, n_run_frac=0.15, short_frac=0.25, lowercase_frac=0.05, junk_frac=0.05)
+        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=3, **keys) as hip:
+            for alg in (host.SW, host.NW):
+                got = hip.compute_alignments(alg, reads, refs, normalise=False)
+                _same_alignments(got, cpu_ref.align(alg, reads, refs, sc, threads=8, **okw), ("strip_k", k, mode, alg, R, F))
+
+
+@pytest.mark.parametrize("k", [12, 16])
+def test_int32_strip_kernels_at_every_strip_height(monkeypatch, k):
+    """... and the int32 kernel of the reference's own model (NW variant, linear gaps) at 12 and 16 rows per lane (every other
+    int32 mode has 8 only, which test_int32_alignment_cells_every_mode_forced runs)."""
+    debug_switches(monkeypatch, strip_k=k, wide_align=1)
+    R, F, n = 2300, 1700, 7
+    reads, refs = synth.make_pairs(n, R, F, seed=203, indel_rate=0.02, n_run_frac=0.15, short_frac=0.25)
+    with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=3) as hip:
+        got = hip.compute_alignments(host.NW, reads, refs, normalise=False)
+    _same_alignments(got, cpu_ref.align(host.NW, reads, refs, threads=8), ("int32 strip_k", k))
+
+
 def test_alignment_scores_beyond_int32_bound_refused():
     """(R + F) * |score| near 2^28: refused with a message, as every range check."""
     R, F = 16000, 16000

@@ -18,9 +18,12 @@ def main():
     ap.add_argument("--geoms", default="0x0")
     ap.add_argument("--policy", type=int, default=0, help="1: SSE/AVX tie-breaks")
     ap.add_argument("--models", default="linear,affine", help="gap models to time (affine: open -5, extend -1; BASELINE config 3)")
+    ap.add_argument("--R", type=int, default=bench.R)
+    ap.add_argument("--F", type=int, default=bench.F)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    reads, refs = bench.synth_on_device(a.pairs, dev, seed=2000)
+    bench.R, bench.F = a.R, a.F                     # (other shapes: reads beyond 2048 rows take the row strips)
+    reads, refs = bench.synth_on_device(a.pairs, dev, seed=2000, R=a.R, F=a.F)
     AL = bench.R + bench.F
     rows = torch.empty((a.pairs, 2, AL), dtype=torch.uint8, device=dev)
     idx = torch.empty((a.pairs, 4), dtype=torch.int16, device=dev)

@@ -176,7 +176,7 @@ public:
         const char *env = getenv("VALIGN_HIP_DEBUG");
         if (!env) return;
         static const char *const known[] = {"no_sym", "no_tag", "no_f16", "no_fused", "no_prof_key", "no_overlap", "no_band_chain",
-                                            "force_long", "wide_align", "no_direct_out", "ragged_min", "chunk_bytes",
+                                            "force_long", "wide_align", "strip_k", "no_direct_out", "ragged_min", "chunk_bytes",
                                             "align_chunk_bytes", "direct_bytes", "scratch_cap_mb", "whole_rows", "short_strips"};
         std::string s(env);
         for (size_t at = 0; at <= s.size();) {
@@ -610,6 +610,7 @@ private:
     bool whole_rows_ = dbg_.on("whole_rows");         // result rows cross PCIe whole (A/B of the device-side packing)
     bool no_direct_out_ = dbg_.on("no_direct_out");   // stage + scatter even into registered result buffers
     bool no_overlap_ = dbg_.on("no_overlap");   // tracebacks in stream order behind their fills
+    int strip_k_ = (int)dbg_.value("strip_k", 0);                  // rows per lane of the strip alignment kernels (16 / 12 / 8): tests
     long long scratch_cap_mb_ = dbg_.value("scratch_cap_mb", 0);   // small pointer scratch: chunked alignment batches in tests (key: pointer_scratch_cap_mb)
     hipStream_t trace_stream_ = nullptr;                          // helper stream of align_device (walks beside the next fill)
     bool chain_regions_busy_[2] = {false, false};                 // WalkChain: the region's last walk may still be running

@@ -26,16 +26,18 @@ struct StripGeometry {
 #define VALIGN_STRIP_WIDE_NW(K) {{nullptr, nullptr, nullptr}, {(const void *)&align_strip_wide_kernel<K, kAlgNW>, nullptr, nullptr}}
 #define VALIGN_STRIP_WIDE_NONE {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}
 #define VALIGN_STRIP_SSE(K) {(const void *)&align_strip_kernel<K, kAlgSW, false, true>, (const void *)&align_strip_kernel<K, kAlgNW, false, true>}
+template <int K>
+static WaveLds strip_lds(int, int) {            // the profile of 64 K rows and the ring of slab numbers: no term in F
+    return WaveLds{StripLds<K>::kRing, 0, StripLds<K>::kTotal};
+}
 static const StripGeometry kStripGeometries[] = {
-    {32, &wave_lds<64, 32>, {(const void *)&align_strip_kernel<32, kAlgSW>, (const void *)&align_strip_kernel<32, kAlgNW>}, {nullptr, nullptr}, {nullptr, nullptr}, VALIGN_STRIP_WIDE_NONE},
-    {24, &wave_lds<64, 24>, {(const void *)&align_strip_kernel<24, kAlgSW>, (const void *)&align_strip_kernel<24, kAlgNW>}, {nullptr, nullptr}, VALIGN_STRIP_SSE(24), VALIGN_STRIP_WIDE_NONE},
-    {16, &wave_lds<64, 16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
+    {16, &strip_lds<16>, {(const void *)&align_strip_kernel<16, kAlgSW>, (const void *)&align_strip_kernel<16, kAlgNW>},
      {(const void *)&align_strip_kernel<16, kAlgSW, true>, (const void *)&align_strip_kernel<16, kAlgNW, true>}, VALIGN_STRIP_SSE(16),
      VALIGN_STRIP_WIDE_NW(16)},
-    {12, &wave_lds<64, 12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
+    {12, &strip_lds<12>, {(const void *)&align_strip_kernel<12, kAlgSW>, (const void *)&align_strip_kernel<12, kAlgNW>},
      {(const void *)&align_strip_kernel<12, kAlgSW, true>, (const void *)&align_strip_kernel<12, kAlgNW, true>}, VALIGN_STRIP_SSE(12),
      VALIGN_STRIP_WIDE_NW(12)},
-    {8, &wave_lds<64, 8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
+    {8, &strip_lds<8>, {(const void *)&align_strip_kernel<8, kAlgSW>, (const void *)&align_strip_kernel<8, kAlgNW>},
      {(const void *)&align_strip_kernel<8, kAlgSW, true>, (const void *)&align_strip_kernel<8, kAlgNW, true>}, VALIGN_STRIP_SSE(8),
      VALIGN_STRIP_WIDE_ALL(8)},
 };
@@ -109,7 +111,9 @@ bool Engine::align_device(int opt, long long n, const uint8_t *d_reads, const ui
     if (alg > 1 || n <= 0) return false;
     // Alignments whose cells leave int16 (the reference's shorts would wrap): int32 cells on the row-strip path, one pair per
     // register (align_strip_wide_kernel) -- every mode; only scores so large that (R + F) * |score| nears 2^28 are refused
-    const bool border_bad = alg == kAlgNW && (long long)(R_ + 1) * std::min({sc_.gap_ref, sc_.open_ref, sc_.ext_ref, 0}) < (sc_.affine ? -15000 : -32000);
+    // (column 0 of the NW variant: a gap of the whole read -- linear (R + 1) gap_ref; affine open_ref + R ext_ref, which
+    // check_int16_range covers)
+    const bool border_bad = alg == kAlgNW && !sc_.affine && (long long)(R_ + 1) * std::min(sc_.gap_ref, 0) < -32000;
     bool in_range = true;
     try {
         check_int16_range(alg);
@@ -365,22 +369,26 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
     if (sse_policy_ && affine)
         throw std::runtime_error("traceback_policy = 1 (SSE/AVX tie-breaks) exists for the linear gap model only");
     const int wide_mode = affine ? 1 : (sse_policy_ ? 2 : 0);
+    // 16 rows per lane unless fewer leave less padding: 1 024-row strips cost 136 ms where 768-row strips cost 152 and 512-row
+    // strips 156 (10 kbp x 10 kbp, 4 096 pairs; 24 and 32 rows per lane -- 218 / 221 ms, two waves per SIMD by their
+    // registers -- are gone).  LDS no longer depends on the shape: the profile of the strip's rows and a 256-byte ring.
     const StripGeometry *geo = nullptr;
     WaveLds lds{};
-    for (int budget : {kMaxBlockLds / 2, kMaxBlockLds}) {            // two waves per CU if possible
-        for (const StripGeometry &g : kStripGeometries) {
-            if (affine && !g.affine_kernel[alg]) continue;
-            if (sse_policy_ && !g.sse_kernel[alg]) continue;
-            if (wide && !g.wide_kernel[alg][wide_mode]) continue;
-            const WaveLds w = g.lds(64 * g.K, F_);
-            if (w.total <= budget && !geo) {
-                geo = &g;
-                lds = w;
-            }
+    double best_cost = 0.0;
+    for (const StripGeometry &g : kStripGeometries) {
+        if (affine && !g.affine_kernel[alg]) continue;
+        if (sse_policy_ && !g.sse_kernel[alg]) continue;
+        if (wide && !g.wide_kernel[alg][wide_mode]) continue;
+        if (strip_k_ && g.K != strip_k_) continue;
+        const int rows_g = 64 * g.K;
+        const double cost = (double)((R_ + rows_g - 1) / rows_g) * rows_g * (g.K == 16 ? 1.0 : (g.K == 12 ? 1.115 : 1.147));
+        if (!geo || cost < best_cost) {
+            geo = &g;
+            lds = g.lds(rows_g, F_);
+            best_cost = cost;
         }
-        if (geo) break;
     }
-    if (!geo) throw std::runtime_error("ref_length " + std::to_string(F_) + " does not fit the LDS of one CU");
+    if (!geo) throw std::runtime_error("no strip alignment kernel for this mode");
     const int K = geo->K, rows = 64 * K, AL = R_ + F_;
     const int strips = std::max(1, (R_ + rows - 1) / rows), pad_total = strips * rows - R_;
     const int blocks8 = (F_ + 63 + 7) / 8;
@@ -391,7 +399,9 @@ void Engine::align_strips_device(int alg, long long n, const uint8_t *d_reads, c
     const size_t bytes_per_pp = strip_words * 4 * strips + (size_t)2 * row_sets * row_dwords * 4;
     size_t free_b = 0, total_b = 0;
     hip_check(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
-    size_t cap = std::min<size_t>(24ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
+    // (the pointer stream of a 10 kbp x 10 kbp pair-of-pairs is 50 MB: what fits the scratch is what runs side by side --
+    // 24 GB, the bound until round 4, kept 480 waves on 1 024 SIMDs; half of the free HBM, at most 128 GB, now)
+    size_t cap = std::min<size_t>(128ull << 30, std::max<size_t>((free_b + trace_bytes_) / 2, 256ull << 20));
     if (scratch_cap_mb_ > 0) cap = std::min<size_t>(cap, (size_t)scratch_cap_mb_ << 20);
     long long chunk = std::max<long long>(2, (long long)(cap / bytes_per_pp) * 2);
     chunk = std::min(chunk, (n + 1) / 2 * 2);

@@ -147,8 +147,15 @@ void Engine::check_int16_range(int alg, bool score_path) const {
     if (score_path && alg == kAlgNW && !plan_.long_mode) hi += nw_tilt_span(widest_sweep_rows(), F_);
     const int worst_gap = std::min({sc_.gap_read, sc_.gap_ref, sc_.open_read, sc_.open_ref, sc_.ext_read, sc_.ext_ref, 0});
     // SW cells are >= 0; NW-variant score cells are bounded below by the cheaper border path
-    const long long lo = alg == kAlgSW ? (long long)std::min(sc_.mismatch, 0) + worst_gap
-                                       : (long long)(std::min(R_, F_) + 2) * std::min(worst_gap, std::min(sc_.mismatch, 0));
+    long long lo = alg == kAlgSW ? (long long)std::min(sc_.mismatch, 0) + worst_gap
+                                 : (long long)(std::min(R_, F_) + 2) * std::min(worst_gap, std::min(sc_.mismatch, 0));
+    // NW-variant alignments with affine gaps (plain frame, "minus infinity" = -16384): row 0 is free, so every H is at least a
+    // gap straight down from it -- open_ref + (R - 1) ext_ref -- and E / F lie at most one opening below an H; a candidate
+    // adds one mismatch.  (The product above charged every step an opening: -50 010 for 10 kbp reads at -5 / -1, whose cells
+    // never go below -10 010.)
+    if (!score_path && sc_.affine && alg == kAlgNW)
+        lo = (long long)std::min(sc_.open_ref, 0) + (long long)R_ * std::min(sc_.ext_ref, 0) + std::min({sc_.open_read, sc_.open_ref, 0}) +
+             std::min(sc_.mismatch, 0);
     if (hi > 32000 || lo < -32000 || (sc_.affine && alg == kAlgNW && lo < -15000))
         throw std::runtime_error("shape x scoring can leave the int16 range of the DP cells (read_length " +
                                  std::to_string(R_) + ", ref_length " + std::to_string(F_) + ")");

@@ -81,6 +81,79 @@ first_invalid_kernel(const uint8_t *reads, const uint8_t *refs, long long n, int
 }
 #endif
 
+// ---- LDS of a strip sweep (round 4): the profile of the strip's 64 K rows and a RING of reference slab numbers ----
+// Up to round 4 a wave staged both references whole (2 F bytes) and kept their slab numbers for every column (2 F more):
+// 40 KB at 10 kbp whatever K -- four waves per CU.  A lane needs the slab numbers of ONE column per step and the wave's
+// lanes span 64 columns: a ring of 128 columns (256 bytes) is refilled 64 columns at a time, one lane per column, from
+// bytes requested one block of 64 steps earlier.  LDS is then the profile alone -- 9.2 / 13.8 / 18.4 KB at K = 8 / 12 /
+// 16 -- and what runs side by side is bounded by registers and by the pointer scratch.
+constexpr int kStripRingCols = 128;
+template <int K>
+struct StripLds {
+    using geo = Geo<64, K>;
+    static constexpr int kRing = (geo::kProfBytes + 255) / 256 * 256;         // 256-aligned: the address is base | offset
+    static constexpr int kTotal = kRing + 2 * kStripRingCols;
+};
+
+// Query profile of the strip's rows (as wave_setup builds it) and an all-"no base" ring.  One wave per block.
+template <int K>
+__device__ __forceinline__ bool strip_ring_setup(const uint8_t *reads, long long n, int R, int F, short match, short mismatch,
+                                                 int strip_row0, WaveTables &w) {
+    using geo = Geo<64, K>;
+    const int lane = threadIdx.x;
+    const long long pair0 = (long long)blockIdx.x * geo::kPairs;
+    if (pair0 >= n) return false;
+    long long pair_end = pair0 + geo::kPairs;
+    if (pair_end > n) pair_end = n;
+    const int last = (int)(pair_end - pair0) - 1;
+    unsigned char *prof = valign_smem;
+    unsigned char *ring = valign_smem + StripLds<K>::kRing;
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) {                   // kPairs * kRows = 128 K items: 2 K per lane
+        const int idx = lane + kWave * i;
+        const int p = idx / geo::kRows, rr = idx - p * geo::kRows;
+        const int ps = p > last ? last : p;
+        const int pos = strip_row0 + rr;
+        const int a = (pos >= 0 && pos < R) ? base_class(reads[(pair0 + ps) * R + pos]) : 0;
+        const bool valid = a >= 1 && a <= 4;
+        const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = valid ? (a == c + 1 ? match : mismatch) : (short)0;
+    }
+    for (int idx = lane; idx < geo::kPairStride / 4; idx += kWave) reinterpret_cast<unsigned *>(prof + geo::kZeroSlab * geo::kPairStride)[idx] = 0u;
+    for (int idx = lane; idx < 2 * kStripRingCols / 4; idx += kWave)
+        reinterpret_cast<unsigned *>(ring)[idx] = 0x01010101u * (unsigned)geo::kZeroSlab;
+    __syncthreads();
+    w.prof = prof;
+    w.refc = ring;
+    w.first_bad = nullptr;
+    w.pair0 = pair0;
+    w.last = last;
+    w.cols_used = F;                                    // (no scan of the references: Smith-Waterman sweeps every column)
+    return true;
+}
+
+// The ring's side of a sweep: `commit` files the slab numbers of columns [t, t + 64) -- lane -> column t + lane -- from the
+// bytes requested a block earlier, `request` asks for the next 64 columns' bytes.
+struct StripRefBytes {
+    unsigned a, b;
+};
+template <int K>
+__device__ __forceinline__ void strip_ring_commit(unsigned char *ring, int col, int F, StripRefBytes raw) {
+    using geo = Geo<64, K>;
+    const int ca = col < F ? base_class(raw.a) : 0, cb = col < F ? base_class(raw.b) : 0;
+    const unsigned sa = (ca >= 1 && ca <= 4) ? (unsigned)(ca - 1) * geo::kPairs : (unsigned)geo::kZeroSlab;
+    const unsigned sb = (cb >= 1 && cb <= 4) ? (unsigned)(cb - 1) * geo::kPairs + 1u : (unsigned)geo::kZeroSlab;
+    *reinterpret_cast<unsigned short *>(ring + 2 * (col & (kStripRingCols - 1))) = (unsigned short)(sa | (sb << 8));
+}
+__device__ __forceinline__ StripRefBytes strip_ring_request(const uint8_t *ref_a, const uint8_t *ref_b, int col, int F) {
+    StripRefBytes r;
+    r.a = col < F ? ref_a[col] : 0u;
+    r.b = col < F ? ref_b[col] : 0u;
+    return r;
+}
+
 // SSE: the tie-breaks of the reference's SSE2 / AVX2 kernels (traceback_policy = 1; linear gaps): stored states 3 DIAG
 // (only between two ACGT bases) > 2 LEFT > 1 UP > 0 START, no zero-floor arithmetic on the gap terms (a floored cell
 // whose neighbours lie below zero is START), as align_fill_sse_kernel (src/Kernels/AVX-SSE/SSEKernel.cpp:366-379, 646-659).
@@ -98,13 +171,15 @@ align_strip_kernel(const StripArgs args) {
     const int row0 = args.strip * geo::kRows - pad_total;           // read position of this strip's first row
 
     WaveTables w;
-    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                 args.wave_lds, args.match, args.mismatch, w, false, blockIdx.x, 0, row0))
-        return;
-    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+    if (!strip_ring_setup<K>(args.reads, args.n, R, args.F, args.match, args.mismatch, row0, w)) return;
+    const int F = args.F;
 
     const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
-    unsigned code_addr = lds_offset(w.refc) - 2 * l;
+    // slab numbers of this lane's column: ring entry (j mod 128), two bytes (pair A, pair B)
+    const unsigned ring_base = lds_offset(w.refc);
+    unsigned code_addr = ring_base | ((unsigned)(-2 * l) & (2u * kStripRingCols - 1u));
+    const uint8_t *ref_a = args.refs + w.pair0 * args.F, *ref_b = args.refs + (w.pair0 + (w.last >= 1 ? 1 : 0)) * args.F;
+    StripRefBytes ref_raw = strip_ring_request(ref_a, ref_b, lane, F);         // columns [0, 64)
 
     const s16x2 g_read = pk(ALG == kAlgSW ? (short)-args.gap_read : args.gap_read);
     const s16x2 g_ref = pk(ALG == kAlgSW ? (short)-args.gap_ref : args.gap_ref);
@@ -191,6 +266,8 @@ align_strip_kernel(const StripArgs args) {
                 topf_cur = topf_next;
                 topf_next = (has_top && t + 64 + lane < args.row_dwords) ? top_f[t + 64 + lane] : border_f_bits;
             }
+            strip_ring_commit<K>(w.refc, t + lane, F, ref_raw);                // columns [t, t + 64): lane 0 needs column t now
+            ref_raw = strip_ring_request(ref_a, ref_b, t + 64 + lane, F);
         }
         const s16x2 diag0 = up0;
         const unsigned above = (unsigned)__builtin_amdgcn_readlane((int)top_cur, t & 63);      // H(row above, column t)
@@ -360,7 +437,7 @@ align_strip_kernel(const StripArgs args) {
             }
         }
         ++j;
-        code_addr += 2;
+        code_addr = ((code_addr + 2u) & (2u * kStripRingCols - 1u)) | ring_base;
     }
 
     // ---- end cell ----
@@ -453,11 +530,11 @@ align_strip_wide_kernel(const StripArgs args) {
     const int strip_pad = args.strip * geo::kRows;
 
     WaveTables w;
-    if (!wave_setup<G, K, false>(args.reads, args.refs, args.n, R, args.F, args.prof_area, args.refc_stride,
-                                 args.wave_lds, args.match, args.mismatch, w, false, blockIdx.x, 0, row0))
-        return;
-    const int F = (ALG == kAlgSW) ? w.cols_used : args.F;
+    if (!strip_ring_setup<K>(args.reads, args.n, R, args.F, args.match, args.mismatch, row0, w)) return;
+    const int F = args.F;
     const unsigned lane_base = lds_offset(w.prof) + l * geo::kLaneBytes;
+    const unsigned ring_base = lds_offset(w.refc);
+    const uint8_t *ref_a = args.refs + w.pair0 * args.F, *ref_b = args.refs + (w.pair0 + (w.last >= 1 ? 1 : 0)) * args.F;
     // Smith-Waterman: magnitudes for the floor-at-zero subtract (as align_strip_kernel); NW variant: signed addends
     const int g_read = ALG == kAlgSW && !SSE ? -args.gap_read : args.gap_read, g_ref = ALG == kAlgSW && !SSE ? -args.gap_ref : args.gap_ref;
     const int o_read = ALG == kAlgSW ? -args.open_read : args.open_read, e_read = ALG == kAlgSW ? -args.ext_read : args.ext_read;
@@ -518,7 +595,8 @@ align_strip_wide_kernel(const StripArgs args) {
         int up0 = 0;                                        // row above the strip at column -1
         if (ALG == kAlgNW && l == 0 && row0 - 1 >= 0) up0 = AFFINE ? args.open_ref + (row0 - 1) * args.ext_ref : row0 * args.gap_ref;
         int j = -l;
-        unsigned code_addr = lds_offset(w.refc) - 2 * l;
+        unsigned code_addr = ring_base | ((unsigned)(-2 * l) & (2u * kStripRingCols - 1u));
+        StripRefBytes ref_raw = strip_ring_request(ref_a, ref_b, lane, F);     // columns [0, 64) (each pass starts the ring over)
         unsigned top_cur = 0u, top_next = has_top ? top[lane] : 0u;
         unsigned topf_cur = (unsigned)border_f, topf_next = (AFFINE && has_top) ? top_f[lane] : (unsigned)border_f;
         unsigned bot_acc = 0u, botf_acc = 0u;
@@ -531,6 +609,8 @@ align_strip_wide_kernel(const StripArgs args) {
                     topf_cur = topf_next;
                     topf_next = (has_top && t + 64 + lane < args.row_dwords) ? top_f[t + 64 + lane] : (unsigned)border_f;
                 }
+                strip_ring_commit<K>(w.refc, t + lane, F, ref_raw);
+                ref_raw = strip_ring_request(ref_a, ref_b, t + 64 + lane, F);
             }
             const int diag0 = up0;
             const int above = __builtin_amdgcn_readlane((int)top_cur, t & 63);
@@ -627,7 +707,7 @@ align_strip_wide_kernel(const StripArgs args) {
                 }
             }
             ++j;
-            code_addr += 2;
+            code_addr = ((code_addr + 2u) & (2u * kStripRingCols - 1u)) | ring_base;
         }
 
         // ---- end cell ----
