@@ -180,7 +180,8 @@ int valign_hip_score_device(valign_hip_engine *e, int opt, long long n, const vo
  * (readStart, readEnd, refStart, refEnd), i.e. the contents of the ABI's `Alignment`
  * (include/AlignmentKernel.h:12-18) flattened.  Tie-breaks follow the Default kernel.
  * Asynchronous on `hip_stream`; uses an internal pointer scratch (20.8 KB per pair at
- * 150x500; up to 24 GiB or half the free HBM per launch, larger batches run in chunks).            */
+ * 150x500, 25 MB at 10 kbp x 10 kbp; up to half the free HBM per launch -- at most 64 GiB for
+ * reads of up to 2048 rows, 128 GiB for row strips --, larger batches run in chunks).                */
 int valign_hip_align_device(valign_hip_engine *e, int opt, long long n, const void *d_reads,
                             const void *d_refs, void *d_rows, void *d_idx, void *hip_stream);
 
