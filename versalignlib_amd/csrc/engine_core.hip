@@ -153,7 +153,7 @@ void Engine::check_int16_range(int alg, bool score_path) const {
     // gap straight down from it -- open_ref + (R - 1) ext_ref -- and E / F lie at most one opening below an H; a candidate
     // adds one mismatch.  (The product above charged every step an opening: -50 010 for 10 kbp reads at -5 / -1, whose cells
     // never go below -10 010.)
-    if (!score_path && sc_.affine && alg == kAlgNW)
+    if ((!score_path || plan_.long_mode) && sc_.affine && alg == kAlgNW)       // (the long-read score kernels: the same plain frame)
         lo = (long long)std::min(sc_.open_ref, 0) + (long long)R_ * std::min(sc_.ext_ref, 0) + std::min({sc_.open_read, sc_.open_ref, 0}) +
              std::min(sc_.mismatch, 0);
     if (hi > 32000 || lo < -32000 || (sc_.affine && alg == kAlgNW && lo < -15000))
