@@ -83,7 +83,7 @@ public:
             if (i < streams_.size() && streams_[i]) (void)hipStreamDestroy(streams_[i]);
             if (i < comms_.size() && comms_[i] && destroy_) (void)destroy_(comms_[i]);
         }
-        if (lib_) dlclose(lib_);
+        // (librccl.so stays loaded: a collective library with service threads is not something to unmap under them)
     }
     // shard buffer of device i: `per` scores (the all-gather needs equal counts: the last shard's tail is padding)
     void reserve(int per) { ensure(per); }                                   // (before the shard threads start)

@@ -339,7 +339,9 @@ void vh_close(vh_plugin *p) {
         guarded("delete_alignment_kernel", [&] { p->destroy(p->kernel); });
         p->kernel = nullptr;
     }
-    if (p->dl) dlclose(p->dl);
+    // The library stays loaded, as under the reference's host (src/util/versalignUtil.cpp:45-76 never closes a kernel
+    // library): a plugin that owns device state, worker threads and registered code objects is not something to map and
+    // unmap once per kernel object.
     delete p;
 }
 

@@ -5,9 +5,12 @@
 only to own device memory and streams.  There is no CPU fallback: constructing an
 Engine without a gfx950 device raises.
 """
+import atexit
 import ctypes
 import json
 import os
+import sys
+import weakref
 
 from . import build as _build
 
@@ -15,6 +18,26 @@ SW = 0
 NW = 1
 
 _lib = None
+
+# Objects that own a handle of the native library.  They are closed by an atexit hook -- while the interpreter, ctypes and
+# the HIP runtime are all still whole -- instead of by finalizers that the interpreter's shutdown runs in no particular
+# order (a finalizer that frees device memory after the runtime's own teardown ends the process with an abort).
+_live = weakref.WeakSet()
+
+
+def _track(obj):
+    _live.add(obj)
+
+
+def _close_all():
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 class HipKernelError(RuntimeError):
@@ -117,6 +140,7 @@ class Engine:
         if rc != 0:
             self._h = None
             raise HipKernelError(_err())
+        _track(self)
 
     def set_traceback_policy(self, policy):
         """0: Default-kernel tie-breaks (default); 1: SSE/AVX-kernel tie-breaks."""
@@ -242,6 +266,8 @@ class Engine:
             self._h = None
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():      # interpreter shutdown: the atexit hook has closed what was open
+            return
         try:
             self.close()
         except Exception:

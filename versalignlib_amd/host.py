@@ -6,8 +6,11 @@ dlopen, set_parameters, set_logger, spawn_alignment_kernel (src/util/versalignUt
 call the two virtuals of include/AlignmentKernel.h:40-43.  Any versalignLib plugin works:
 the reference's CPU kernels and this repo's libHIPKernel.so are swapped by path.
 """
+import atexit
 import ctypes
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -17,6 +20,20 @@ SW = 0   # opt & 0xF == 0: Smith-Waterman
 NW = 1   # opt & 0xF == 1: the reference's Needleman-Wunsch variant
 
 _lib = None
+
+# (as hipkernel.py: open plugins are closed by an atexit hook, not by finalizers at interpreter shutdown)
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 def lib():
@@ -92,6 +109,7 @@ class Plugin:
         self._h = lib().vh_open(os.fsencode(so_path))
         if not self._h:
             raise PluginError(_err())
+        _live.add(self)
         self.read_length = int(read_length)
         self.ref_length = int(ref_length)
         self.set_params(read_length=read_length, ref_length=ref_length, **params)
@@ -188,6 +206,8 @@ class Plugin:
         self.close()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():      # interpreter shutdown: the atexit hook has closed what was open
+            return
         try:
             self.close()
         except Exception:
