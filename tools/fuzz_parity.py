@@ -21,8 +21,8 @@ from oracle import cpu_ref                                          # noqa: E402
 from versalignlib_amd import build, host, synth                    # noqa: E402
 
 
-def draw_case(rng, big=False):
-    kind = "big" if big else rng.choice(["short", "short", "short", "mid", "long", "tiny"])
+def draw_case(rng, big=False, kinds=None):
+    kind = "big" if big else rng.choice(kinds or ["short", "short", "short", "mid", "long", "tiny"])
     if kind == "big":                                     # many pairs: the chunked host pipeline, tail chunks, every slot
         R, F = int(rng.integers(30, 200)), int(rng.integers(60, 600))
     elif kind == "tiny":
@@ -31,8 +31,8 @@ def draw_case(rng, big=False):
         R, F = int(rng.integers(8, 400)), int(rng.integers(8, 900))
     elif kind == "mid":
         R, F = int(rng.integers(400, 2100)), int(rng.integers(200, 3000))
-    else:
-        R, F = int(rng.integers(2049, 5000)), int(rng.integers(100, 5000))
+    else:                                                 # row strips (alignments), long-read score kernels
+        R, F = int(rng.integers(2049, 6000)), int(rng.integers(1, 5000))
     cells = R * F
     n = int(max(1, min(rng.integers(1, 400), 6_000_000 // max(cells, 1))))
     if kind == "big":
@@ -130,13 +130,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--big-every", type=int, default=0, help="every K-th case has 40k-300k pairs (0: none)")
+    ap.add_argument("--kinds", default="", help="comma-separated shape kinds to draw from (tiny, short, mid, long); default: a mix")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     i = 0
     done = 0
     while time.time() - t0 < a.seconds or (a.only >= 0 and i <= a.only):
-        c = draw_case(rng, big=a.big_every > 0 and i % a.big_every == a.big_every - 1)
+        c = draw_case(rng, big=a.big_every > 0 and i % a.big_every == a.big_every - 1, kinds=a.kinds.split(",") if a.kinds else None)
         if a.only < 0 or i == a.only:
             try:
                 err = run_case(c)
