@@ -255,14 +255,20 @@ def test_full_size_properties_config3():
     eng.close()
 
 
-@pytest.mark.parametrize("R,F,n", [(2000, 1200, 24), (1500, 2500, 16), (700, 3000, 33)])
-def test_largest_register_geometries(R, F, n):
-    """Reads of up to 2048 rows still take the register sweep (64 lanes per pair, 12-32 rows per lane):
-    scores and alignments of both modes against the oracle."""
+@pytest.mark.parametrize("R,F,n,K", [(2000, 1200, 24, 32), (1500, 2500, 16, 24), (700, 3000, 33, 12), (2000, 1200, 24, 0), (1500, 2500, 16, 0)])
+def test_largest_register_geometries(R, F, n, K):
+    """Reads of up to 2048 rows fit the register sweep (64 lanes per pair, 12-32 rows per lane).  Since round 4 the engine
+    prefers the long-read kernels beyond 1536 rows (scores) / row strips beyond 1024 rows (alignments) -- measured faster,
+    profiles/r04_rate_sweep.txt --, so the tall register geometries are exercised by forcing them (K > 0) and the engine's
+    own choice beside them (K = 0): scores and alignments of both modes against the oracle."""
     import torch
     reads, refs = synth.make_pairs(n, R, F, seed=R, indel_rate=0.01, n_run_frac=0.1, short_frac=0.2)
-    eng = hipkernel.Engine(R, F)
-    assert eng.describe()["group_lanes"] == 64 and not eng.describe()["long_mode"]
+    eng = hipkernel.Engine(R, F, group_lanes=64 if K else 0, rows_per_lane=K)
+    d = eng.describe()
+    if K:
+        assert d["group_lanes"] == 64 and d["rows_per_lane"] == K and not d["long_mode"]
+    else:
+        assert d["long_mode"] == (1 if R > 1536 else 0)
     d_reads, d_refs = torch.from_numpy(reads).cuda(), torch.from_numpy(refs).cuda()
     for opt in (host.SW, host.NW):
         rows, idx = eng.align_device(opt, d_reads, d_refs)

@@ -132,7 +132,10 @@ bool Engine::align_device(int opt, long long n, const uint8_t *d_reads, const ui
         return false;
     }
     hip_check(hipSetDevice(device_), "hipSetDevice");
-    if (plan_.long_mode) {
+    // row strips: reads beyond one register sweep, and -- measured, profiles/r04_rate_sweep.txt -- reads of more than 1 024
+    // rows, whose resident geometries (64 x 24 / 64 x 32: 34 to 53 KB of LDS) fill at 0.8-2.1 TCUPS where 12- or 16-row
+    // strips at eight waves per CU do 1.6-2.3 (1 200 x 3 000: 41 / 74 ms -> 26 / 37 ms, linear / affine)
+    if (plan_.long_mode || (!force_g_ && !force_k_ && R_ > 1024)) {
         align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
         return false;
     }
