@@ -28,6 +28,14 @@ Engine::Engine(int device, int R, int F, const Scoring &sc, int force_g, int for
     // kernels (512-row strips, 12 to 15 waves per CU) sweep them 15 to 55 % faster (2 000 x 4 000: 6.2 -> 7.9 TCUPS linear,
     // 3.6 -> 5.6 affine; profiles/r04_rate_sweep.txt).  A forced geometry is a forced geometry.
     if (!force_g && !force_k && !plan_.long_mode && plan_.geo && plan_.geo->G * plan_.geo->K > 1536) plan_ = long_plan();
+    // The resident kernels keep the slab numbers of the whole reference in LDS (2 ref_length bytes per lane group, and as
+    // much again to stage it): at 150 x 8 000 one wave fills a CU's LDS -- 2.3 TCUPS, 0.7 at 150 x 32 000 -- where the
+    // long-read kernels, whose slab numbers go through a ring, sweep 8.2 / 7.8 (affine: 1.5 / 0.4 against 4.5 / 3.0).  One
+    // wave per CU: always; two: for linear gaps (500 x 20 000: 4.8 -> 6.4; affine 2.9 against 2.5 stays).
+    if (!force_g && !force_k && !plan_.long_mode && plan_.geo) {
+        const int waves_per_cu = std::min(32, (kMaxBlockLds / std::max(1, plan_.lds.total * plan_.waves_per_block)) * plan_.waves_per_block);
+        if (waves_per_cu <= 1 || (waves_per_cu <= 2 && !sc_.affine)) plan_ = long_plan();
+    }
     latency_plan_ = (force_g || force_k || plan_.long_mode) ? plan_ : choose_plan(R_, F_, 0, 0, true);
     build_length_classes();
     for (int s = 0; s < kSlots; ++s) hip_check(hipStreamCreateWithFlags(&streams_[s], hipStreamNonBlocking), "hipStreamCreate");
