@@ -31,6 +31,8 @@ def draw_case(rng, big=False, kinds=None):
         R, F = int(rng.integers(8, 400)), int(rng.integers(8, 900))
     elif kind == "mid":
         R, F = int(rng.integers(400, 2100)), int(rng.integers(200, 3000))
+    elif kind == "longref":                               # short reads against a reference that starves LDS
+        R, F = int(rng.integers(20, 600)), int(rng.integers(5000, 20000))
     else:                                                 # row strips (alignments), long-read score kernels
         R, F = int(rng.integers(2049, 6000)), int(rng.integers(1, 5000))
     cells = R * F
@@ -130,7 +132,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--big-every", type=int, default=0, help="every K-th case has 40k-300k pairs (0: none)")
-    ap.add_argument("--kinds", default="", help="comma-separated shape kinds to draw from (tiny, short, mid, long); default: a mix")
+    ap.add_argument("--kinds", default="", help="comma-separated shape kinds to draw from (tiny, short, mid, long, longref); default: a mix")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
