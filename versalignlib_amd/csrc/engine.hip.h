@@ -395,6 +395,17 @@ public:
     };
     FillChoice fill_choice(int alg, const Geometry &geo) const;
     const LaunchPlan &align_plan_for(int alg, FillChoice &choice);
+    // The plan compute_alignments starts from: the engine's own -- unless that is the long-read one only because the score
+    // kernels prefer it (a reference that starves LDS) while the read fits a register sweep with two waves per CU or so:
+    // row strips are 512 rows tall, 150-row reads fill a third of them (150 x 4 000: 1.06 TCUPS on strips).
+    const LaunchPlan &align_base_plan() const {
+        if (plan_.long_mode && align_resident_.geo && !align_resident_.long_mode && R_ <= 1024 && align_resident_.lds.total <= 140 * 1024) {
+            const int wpb = align_resident_.waves_per_block;
+            const int waves_per_cu = (kMaxBlockLds / std::max(1, align_resident_.lds.total * wpb)) * wpb;
+            if (waves_per_cu >= 2 || !sc_.affine) return align_resident_;      // (150 x 8 000 affine, one wave per CU: 60 ms against 53 on strips)
+        }
+        return plan_;
+    }
 
     bool align_device(int opt, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows,
                       short *d_idx, hipStream_t stream, const WalkChain *chain = nullptr);
@@ -617,6 +628,7 @@ private:
     hipEvent_t fill_done_[2] = {nullptr, nullptr}, trace_done_[2] = {nullptr, nullptr}, entry_ev_ = nullptr;
     std::string arch_;
     LaunchPlan plan_, latency_plan_;
+    LaunchPlan align_resident_;         // what choose_plan picked before the score path's preferences for the long-read kernels
     LaunchPlan fallback_plan_;          // alignments that need a kernel only the full geometries carry (align_plan_for)
     hipStream_t streams_[kSlots] = {};
     hipEvent_t slot_done_[kSlots] = {};

@@ -97,8 +97,9 @@ Engine::FillChoice Engine::fill_choice(int alg, const Geometry &geo) const {
 // otherwise (a fallback kernel on a geometry compiled with the fast set only, kernel_instances.hip.h) the cheapest FULL
 // geometry that fits the read -- same results, the sweep a few per cent longer.
 const LaunchPlan &Engine::align_plan_for(int alg, FillChoice &choice) {
-    choice = fill_choice(alg, *plan_.geo);
-    if (plan_.geo->fill[alg][choice.kernel]) return plan_;
+    const LaunchPlan &base = align_base_plan();
+    choice = fill_choice(alg, *base.geo);
+    if (base.geo->fill[alg][choice.kernel]) return base;
     if (!fallback_plan_.geo) fallback_plan_ = choose_plan(R_, F_, 0, 0, false, true);
     choice = fill_choice(alg, *fallback_plan_.geo);
     if (!fallback_plan_.geo->fill[alg][choice.kernel]) throw std::runtime_error("no alignment kernel for this mode");
@@ -135,7 +136,7 @@ bool Engine::align_device(int opt, long long n, const uint8_t *d_reads, const ui
     // row strips: reads beyond one register sweep, and -- measured, profiles/r04_rate_sweep.txt -- reads of more than 1 024
     // rows, whose resident geometries (64 x 24 / 64 x 32: 34 to 53 KB of LDS) fill at 0.8-2.1 TCUPS where 12- or 16-row
     // strips at eight waves per CU do 1.6-2.3 (1 200 x 3 000: 41 / 74 ms -> 26 / 37 ms, linear / affine)
-    if (plan_.long_mode || (!force_g_ && !force_k_ && R_ > 1024)) {
+    if (align_base_plan().long_mode || (!force_g_ && !force_k_ && R_ > 1024)) {
         align_strips_device(alg, n, d_reads, d_refs, d_rows, d_idx, stream);
         return false;
     }
@@ -311,7 +312,7 @@ void Engine::ensure_trace_stream() {
 
 bool Engine::align_fused(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, uint8_t *d_rows, short *d_idx,
                  hipStream_t stream) {
-    if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || plan_.long_mode || force_g_ || force_k_ || !tagged_range_ok(alg, 256)) return false;     // (256: the tallest fused geometry)
+    if (no_fused_ || sc_.affine || sse_policy_ || no_tag_ || align_base_plan().long_mode || force_g_ || force_k_ || !tagged_range_ok(alg, 256)) return false;     // (256: the tallest fused geometry)
     if (wide_align_) return false;
     try {
         check_int16_range(alg);

@@ -24,6 +24,7 @@ Engine::Engine(int device, int R, int F, const Scoring &sc, int force_g, int for
     force_g_ = force_g;
     force_k_ = force_k;
     plan_ = choose_plan(R_, F_, force_g, force_k);
+    align_resident_ = plan_;
     // Reads of more than 1 536 rows would take the 64 x 32 geometry -- 45 to 53 KB of LDS, three waves per CU --: the long-read
     // kernels (512-row strips, 12 to 15 waves per CU) sweep them 15 to 55 % faster (2 000 x 4 000: 6.2 -> 7.9 TCUPS linear,
     // 3.6 -> 5.6 affine; profiles/r04_rate_sweep.txt).  A forced geometry is a forced geometry.
