@@ -521,7 +521,11 @@ void Engine::align_host(int opt, int n, const char *const *reads, const char *co
     hip_check(hipSetDevice(device_), "hipSetDevice");
     const int AL = R_ + F_;
     const size_t per_pair = (size_t)3 * AL + 8;
-    long long chunk = per_pair ? (long long)(align_chunk_bytes_ / per_pair) : n;
+    // (row strips run chunk after chunk on one pointer scratch: chunks that fill the device -- 2 000 pairs-of-pairs and more --
+    // instead of 128 MB of staging, which is 1 100 of them at 10 kbp x 10 kbp: 253 -> ~190 ms per 4 096 pairs through the ABI)
+    const bool by_strips = align_base_plan().long_mode || (!force_g_ && !force_k_ && R_ > 1024);
+    const size_t chunk_bytes = by_strips && !dbg_.on("align_chunk_bytes") ? std::max<size_t>(align_chunk_bytes_, 384u << 20) : align_chunk_bytes_;
+    long long chunk = per_pair ? (long long)(chunk_bytes / per_pair) : n;
     chunk = whole_rounds(chunk);
     chunk = std::max<long long>(chunk, 1024);
     chunk = std::min<long long>(chunk, n);
