@@ -202,6 +202,26 @@ def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
     eng.close()
 
 
+@pytest.mark.parametrize("R,F,n,long_scores", [(150, 8000, 33, 1), (150, 4000, 41, 1), (150, 2000, 50, 0), (500, 20000, 9, 1)])
+def test_short_reads_against_long_references(R, F, n, long_scores):
+    """A reference that starves LDS (the resident kernels keep its slab numbers whole: one or two waves per CU from 4 000
+    columns on) sends score_alignments to the long-read kernels, whose slab numbers go through a ring -- and leaves
+    compute_alignments on a resident plan of its own while that one still fits: both against the oracle, linear and affine."""
+    reads, refs = synth.make_pairs(n, R, F, seed=R + F, indel_rate=0.01, n_run_frac=0.1, short_frac=0.2, lowercase_frac=0.05, junk_frac=0.05)
+    eng = hipkernel.Engine(R, F)
+    assert eng.describe()["long_mode"] == long_scores
+    eng.close()
+    for keys, osc, okw in ((dict(), cpu_ref.Scoring.make(), dict()),
+                           (dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5, score_gap_extend_ref=-1),
+                            cpu_ref.Scoring.make(2, -1, -3, -3, -5, -1, -5, -1), dict(affine=True))):
+        with host.Plugin(build.HIP_PLUGIN, R, F, num_threads=4, **keys) as hip:
+            for opt in (host.SW, host.NW):
+                assert np.array_equal(hip.score_alignments(opt, reads, refs), cpu_ref.score(opt, reads, refs, osc, threads=8, **okw)), (opt, keys)
+                rows, idx = hip.compute_alignments(opt, reads, refs, normalise=False)
+                exp_rows, exp_idx = cpu_ref.align(opt, reads, refs, osc, threads=8, **okw)
+                assert np.array_equal(idx, exp_idx) and np.array_equal(rows, exp_rows), (opt, keys)
+
+
 def test_int16_range_is_checked_per_call():
     """A shape whose cells could leave int16 never wraps silently (as the reference would): scores and (since round 4, every
     mode) alignments move to int32 cells."""
