@@ -58,7 +58,7 @@ def draw_case(rng, big=False, kinds=None):
     scale = 1
     if rng.random() < 0.15:                               # scores large enough that cells leave int16: the int32 paths
         scale = int(rng.integers(40, 300))
-        keys = {k: v * scale for k, v in keys.items()}
+        keys = {k: (v * scale if k.startswith("score_") and k != "score_width" else v) for k, v in keys.items()}
         match, mismatch, gr, gf = match * scale, mismatch * scale, gr * scale, gf * scale
         aff = tuple(v * scale for v in aff)
     band = 0
@@ -72,6 +72,12 @@ def draw_case(rng, big=False, kinds=None):
         keys["host_packing"] = 0
     if rng.random() < 0.3:
         keys["num_threads"] = int(rng.integers(1, 9))
+    if rng.random() < 0.15:
+        keys["score_width"] = 32                          # int32 score cells whatever the range
+    if rng.random() < 0.15:
+        keys["half_float_cells"] = int(rng.integers(0, 2))
+    if rng.random() < 0.1:
+        keys["hip_devices"] = 1                           # the in-plugin shard path with one shard
     data = dict(seed=int(rng.integers(1, 1 << 30)), sub_rate=float(rng.choice([0.02, 0.1, 0.3])), indel_rate=float(rng.choice([0.0, 0.02])) if n * R < 400_000 else 0.0,
                 n_run_frac=float(rng.choice([0.0, 0.1])), short_frac=float(rng.choice([0.0, 0.2, 0.6])), lowercase_frac=0.05, junk_frac=0.05)
     return dict(R=R, F=F, n=n, keys=keys, aff=aff, affine=affine, policy=policy, data=data, gaps=(gr, gf), match=match, mismatch=mismatch, band=band)
