@@ -210,6 +210,7 @@ def test_short_reads_against_long_references(R, F, n, long_scores):
     reads, refs = synth.make_pairs(n, R, F, seed=R + F, indel_rate=0.01, n_run_frac=0.1, short_frac=0.2, lowercase_frac=0.05, junk_frac=0.05)
     eng = hipkernel.Engine(R, F)
     assert eng.describe()["long_mode"] == long_scores
+    assert eng.describe(host.SW)["score_cells"] == "f16"        # (round 4: the long-read kernel has half-float cells too, SW / one gap score)
     eng.close()
     for keys, osc, okw in ((dict(), cpu_ref.Scoring.make(), dict()),
                            (dict(score_gap_open_read=-5, score_gap_extend_read=-1, score_gap_open_ref=-5, score_gap_extend_ref=-1),

@@ -110,6 +110,10 @@ const char *Engine::score_cell_format(int alg) const {
     if (!plan_.long_mode && !sc_.affine && ((sc_.gap_read == sc_.gap_ref && !no_sym_) || alg == kAlgNW) && !no_f16_ &&
         (alg == kAlgNW ? half_float_exact(alg, R_, F_, plan_.geo->G * plan_.geo->K) : half_float_unit_exact(R_, F_)))
         return "f16";
+    // (long-read kernels: Smith-Waterman with one gap score on the 160-row strips, engine_long.hip)
+    if (plan_.long_mode && alg == kAlgSW && !sc_.affine && sc_.gap_read == sc_.gap_ref && !no_sym_ && !no_f16_ && band_width_ == 0 &&
+        R_ <= 1024 && half_float_unit_exact(R_, F_))
+        return "f16";
     return "int16";
 }
 

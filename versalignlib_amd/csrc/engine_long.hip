@@ -226,6 +226,10 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
     const bool affine_sym = sc_.open_read == sc_.open_ref && sc_.ext_read == sc_.ext_ref && !no_sym_;
     const bool sym = sc_.affine ? affine_sym : (sc_.gap_read == sc_.gap_ref && !no_sym_);
     const void *fn = geo.kernel[sc_.affine ? 1 : 0][alg][sym ? 1 : 0][wide ? 1 : 0];
+    // half-float cells (score_long_kernel<..., F16>): Smith-Waterman with one gap score on the 160-row strips while every cell
+    // stays below 1024 -- short reads against a reference the resident kernels' LDS cannot hold (150 x 8 000: 8.2 -> ~11 TCUPS)
+    if (&geo == &kLongStrips && alg == kAlgSW && !sc_.affine && sym && !wide && band_width_ == 0 && !no_f16_ && half_float_unit_exact(R_, F_))
+        fn = (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, true>;
     const int long_lds = geo.lds[sc_.affine ? 1 : 0];
     for (long long begin = 0; begin < n; begin += chunk) {
         const long long cnt = std::min(chunk, n - begin);

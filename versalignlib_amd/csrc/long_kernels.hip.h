@@ -114,9 +114,15 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
 // and from strip to strip through a second boundary row next to H's).  SYM then means open_read == open_ref and
 // ext_read == ext_ref: H - open is computed once per cell.
 // (G == 64: LDS lets eleven one-wave blocks share a CU -- ask the compiler for a register budget that lets three waves share a SIMD)
-template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false>
+// F16 (Smith-Waterman, one gap score, int16-packed registers only): the cells are half floats holding value * 2^-10 -- exact
+// while every value stays below 1024, which the engine checks (half_float_unit_exact) -- so that "max(x + g, 0)" is ONE
+// packed add with the clamp modifier and the cell is a three-operand maximum: add, max3, add-clamp per packed register
+// instead of add, max, sub, max, max (score_kernel's kGapSymF16).  What routes here: short reads against a reference too
+// long for the resident kernels' LDS.
+template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false, bool F16 = false>
 __global__ void __launch_bounds__(64, G == 64 ? 3 : 1)
 score_long_kernel(const LongArgs args) {
+    static_assert(!F16 || (ALG == kAlgSW && SYM && !WIDE && !AFFINE), "half-float cells: Smith-Waterman, one gap score, packed");
     using geo = Geo<G, K>;
     using lay = LongLds<G, K, AFFINE>;
     using ops = Cell<WIDE>;
@@ -182,8 +188,9 @@ score_long_kernel(const LongArgs args) {
             const int off = p * geo::kPairStride + geo::row_offset(rr / K, rr % K);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const short sc = valid ? (a == c + 1 ? args.match : args.mismatch) : (short)0;
-                *reinterpret_cast<short *>(prof + c * geo::kPairs * geo::kPairStride + off) = sc;
+                short sc = valid ? (a == c + 1 ? args.match : args.mismatch) : (short)0;
+                if (F16) sc = __builtin_bit_cast(short, (_Float16)((float)sc * (1.0f / 1024.0f)));
+                *reinterpret_cast<short *>(prof + c * geo::kPairStride * geo::kPairs + off) = sc;
             }
         }
         // columns swept by this strip [c_lo, c_hi] and by the previous one [p_lo, p_hi]
@@ -201,9 +208,9 @@ score_long_kernel(const LongArgs args) {
         for (int q = 0; q < K; ++q) Hl[q] = ops::bc(0);
 #pragma unroll
         for (int q = 0; q < ((SYM && WIDE && ALG == kAlgSW) ? K : 1); ++q) Gl[q] = 0;
-        cell_t El[AFFINE ? K : 1];
+        cell_t El[(AFFINE || F16) ? K : 1];     // affine: E of the previous column; F16: max(h + g, 0) of it
 #pragma unroll
-        for (int q = 0; q < (AFFINE ? K : 1); ++q) El[q] = border_f;
+        for (int q = 0; q < ((AFFINE || F16) ? K : 1); ++q) El[q] = border_f;
         // AFFINE && SYM (same open / extend both ways): H - open of the previous column, computed once per cell and
         // shared by E of this column and F of the next row (score_kernel's kGapAffineSym)
         cell_t HOl[(AFFINE && SYM) ? K : 1];
@@ -306,6 +313,31 @@ score_long_kernel(const LongArgs args) {
                         m_cur = m_next;
                     }
                     f_last = f;
+                } else if constexpr (F16) {
+                    auto hf = [](s16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(f16x2, v); };
+                    auto hb = [](f16x2 v) __attribute__((always_inline)) { return __builtin_bit_cast(s16x2, v); };
+                    const _Float16 gs = (_Float16)((float)args.gap_ref * (1.0f / 1024.0f));
+                    const f16x2 g_unit = f16x2{gs, gs}, zero2 = f16x2{(_Float16)0, (_Float16)0}, one2 = f16x2{(_Float16)1, (_Float16)1};
+                    // (the row above arrives as h alone -- from the lane before or from the previous strip's boundary row)
+                    f16x2 up_c = __builtin_elementwise_min(__builtin_elementwise_max(hf(up0) + g_unit, zero2), one2);
+                    f16x2 hh = zero2;
+                    f16x2 d_cur = hf(diag0) + hf(S[0]), d_prev = zero2;
+                    f16x2 bestf = hf(best);
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        f16x2 d_next = d_cur;
+                        if (q + 1 < K) d_next = hf(Hl[q]) + hf(S[q + 1]);       // before Hl[q] is overwritten
+                        hh = __builtin_elementwise_maximum(__builtin_elementwise_maximum(d_cur, hf(El[q])), up_c);
+                        Hl[q] = hb(hh);
+                        up_c = __builtin_elementwise_min(__builtin_elementwise_max(hh + g_unit, zero2), one2);   // v_pk_add_f16 clamp
+                        El[q] = hb(up_c);
+                        if (q & 1) bestf = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bestf, d_prev), d_cur);
+                        else if (q == K - 1) bestf = __builtin_elementwise_maximum(bestf, d_cur);
+                        d_prev = d_cur;
+                        d_cur = d_next;
+                    }
+                    best = hb(bestf);
+                    h = hb(hh);
                 } else if constexpr (SYM && WIDE && ALG == kAlgSW) {
                     // int32 cells have a three-operand maximum and a saturating subtract: each cell keeps
                     // (h, max(h - g, 0)) and h = max3(diag + S, left', up') on the floored registers is
@@ -525,7 +557,10 @@ score_long_kernel(const LongArgs args) {
     }
 
     cell_t res;
-    if (ALG == kAlgSW) {
+    if constexpr (F16) {
+        const f16x2 b = __builtin_bit_cast(f16x2, best);
+        res = s16x2{(short)(int)((float)b.x * 1024.0f), (short)(int)((float)b.y * 1024.0f)};
+    } else if (ALG == kAlgSW) {
         res = best;
     } else {
         res = ops::mx(col_best, l == G - 1 ? row_best : ops::bc(0));
