@@ -202,11 +202,14 @@ def test_half_float_cells_are_exact_up_to_their_limit(match, cells):
     eng.close()
 
 
-@pytest.mark.parametrize("R,F,n,long_scores", [(150, 8000, 33, 1), (150, 4000, 41, 1), (150, 2000, 50, 0), (500, 20000, 9, 1)])
+@pytest.mark.parametrize("R,F,n,long_scores", [(150, 8000, 33, 1), (150, 4000, 41, 1), (150, 2000, 50, 1), (150, 1000, 60, 0), (100, 2000, 50, 0),
+                                                 (500, 20000, 9, 1)])
 def test_short_reads_against_long_references(R, F, n, long_scores):
-    """A reference that starves LDS (the resident kernels keep its slab numbers whole: one or two waves per CU from 4 000
-    columns on) sends score_alignments to the long-read kernels, whose slab numbers go through a ring -- and leaves
-    compute_alignments on a resident plan of its own while that one still fits: both against the oracle, linear and affine."""
+    """A reference that starves LDS (the resident kernels keep its slab numbers whole: four waves per CU at 2 000 columns,
+    one at 8 000) sends score_alignments to the long-read kernels, whose slab numbers go through a ring (single-strip
+    instances, half-float cells for SW with one gap score) -- unless their 160-row strips pad the read worse than the
+    resident geometry (100 rows) -- and leaves compute_alignments on a resident plan of its own while that one still fits:
+    both against the oracle, linear and affine."""
     reads, refs = synth.make_pairs(n, R, F, seed=R + F, indel_rate=0.01, n_run_frac=0.1, short_frac=0.2, lowercase_frac=0.05, junk_frac=0.05)
     eng = hipkernel.Engine(R, F)
     assert eng.describe()["long_mode"] == long_scores

@@ -176,7 +176,7 @@ public:
         const char *env = getenv("VALIGN_HIP_DEBUG");
         if (!env) return;
         static const char *const known[] = {"no_sym", "no_tag", "no_f16", "no_fused", "no_prof_key", "no_overlap", "no_band_chain",
-                                            "force_long", "wide_align", "strip_k", "no_direct_out", "ragged_min", "chunk_bytes",
+                                            "force_long", "wide_align", "strip_k", "no_single_strip", "no_direct_out", "ragged_min", "chunk_bytes",
                                             "align_chunk_bytes", "direct_bytes", "scratch_cap_mb", "whole_rows", "short_strips"};
         std::string s(env);
         for (size_t at = 0; at <= s.size();) {

@@ -31,11 +31,17 @@ Engine::Engine(int device, int R, int F, const Scoring &sc, int force_g, int for
     if (!force_g && !force_k && !plan_.long_mode && plan_.geo && plan_.geo->G * plan_.geo->K > 1536) plan_ = long_plan();
     // The resident kernels keep the slab numbers of the whole reference in LDS (2 ref_length bytes per lane group, and as
     // much again to stage it): at 150 x 8 000 one wave fills a CU's LDS -- 2.3 TCUPS, 0.7 at 150 x 32 000 -- where the
-    // long-read kernels, whose slab numbers go through a ring, sweep 8.2 / 7.8 (affine: 1.5 / 0.4 against 4.5 / 3.0).  One
-    // wave per CU: always; two: for linear gaps (500 x 20 000: 4.8 -> 6.4; affine 2.9 against 2.5 stays).
+    // long-read kernels, whose slab numbers go through a ring, sweep 10.9 / 10.2 (affine: 1.5 / 0.4 against 5.9 / 5.6; their
+    // single-strip instances, profiles/r04_rate_sweep.txt).  One wave per CU: always.  Two: with linear gaps, or when the
+    // 160-row strips pad the read no worse than the resident geometry (150 x 4 000 affine: 2.9 -> 6.0).  Up to four (from about
+    // 1 500 columns on): under the same padding condition (150 x 2 000: 8.7 -> 11.0 / 5.7 -> 6.0; 100 x 2 000 stays: 128 rows
+    // against 160).
     if (!force_g && !force_k && !plan_.long_mode && plan_.geo) {
         const int waves_per_cu = std::min(32, (kMaxBlockLds / std::max(1, plan_.lds.total * plan_.waves_per_block)) * plan_.waves_per_block);
-        if (waves_per_cu <= 1 || (waves_per_cu <= 2 && !sc_.affine)) plan_ = long_plan();
+        const int strip_rows = kLongG * kLongK;
+        // (reads of up to 1 024 rows take the 160-row strips; beyond, the 512-row ones, which the 64 x 24 geometry still beats)
+        const bool pads_alike = R_ <= 1024 && ((R_ + strip_rows - 1) / strip_rows) * strip_rows * 100 <= plan_.geo->G * plan_.geo->K * 115;
+        if (waves_per_cu <= 1 || (waves_per_cu <= 2 && (!sc_.affine || pads_alike)) || (waves_per_cu <= 4 && pads_alike)) plan_ = long_plan();
     }
     latency_plan_ = (force_g || force_k || plan_.long_mode) ? plan_ : choose_plan(R_, F_, 0, 0, true);
     build_length_classes();

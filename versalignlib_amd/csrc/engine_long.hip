@@ -230,7 +230,23 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
     // stays below 1024 -- short reads against a reference the resident kernels' LDS cannot hold (150 x 8 000: 8.2 -> ~11 TCUPS)
     if (&geo == &kLongStrips && alg == kAlgSW && !sc_.affine && sym && !wide && band_width_ == 0 && !no_f16_ && half_float_unit_exact(R_, F_))
         fn = (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, true>;
-    const int long_lds = geo.lds[sc_.affine ? 1 : 0];
+    int long_lds = geo.lds[sc_.affine ? 1 : 0];
+    // a read of ONE strip (short reads sent here for their reference's length): the instances without boundary rings
+    if (&geo == &kLongStrips && a.strips == 1 && !wide && band_width_ == 0 && !dbg_.on("no_single_strip")) {
+        static const void *const single[2][2][2] = {
+            {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, false, false, true>,
+              (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, false, true>},
+             {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, false, false, true>,
+              (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false, false, false, true>}},
+            {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, true, false, true>,
+              (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, true, false, true>},
+             {(const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, false, false, true, false, true>,
+              (const void *)&score_long_kernel<kLongG, kLongK, kAlgNW, true, false, true, false, true>}}};
+        const bool f16 = fn == (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, true>;
+        fn = f16 ? (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, true, true>
+                 : single[sc_.affine ? 1 : 0][alg][sym ? 1 : 0];
+        long_lds = sc_.affine ? LongLds<kLongG, kLongK, true, true>::kTotal : LongLds<kLongG, kLongK, false, true>::kTotal;
+    }
     for (long long begin = 0; begin < n; begin += chunk) {
         const long long cnt = std::min(chunk, n - begin);
         a.reads = d_reads + (size_t)begin * R_;

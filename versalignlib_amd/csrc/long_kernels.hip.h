@@ -76,7 +76,7 @@ struct Cell<true> {
     static __device__ __forceinline__ T from_bits(unsigned v) { return (int)v; }
 };
 
-template <int G, int K, bool AFFINE = false>
+template <int G, int K, bool AFFINE = false, bool SINGLE = false>       // SINGLE: the read is one strip -- no boundary rings
 struct LongLds {
     using geo = Geo<G, K>;
     // The ring of reference slab numbers is read across the whole lane skew: lane G - 1 is G - 1 columns behind lane 0,
@@ -87,7 +87,7 @@ struct LongLds {
     static constexpr int kOut = kIn + geo::kGroups * kRing * 4;           // [groups][kRing] dwords
     static constexpr int kInF = kOut + geo::kGroups * kRing * 4;          // affine: the F values of the boundary rows, same rings
     static constexpr int kOutF = kInF + geo::kGroups * kRing * 4;
-    static constexpr int kTotal = AFFINE ? kOutF + geo::kGroups * kRing * 4 : kInF;      // (LDS bounds the waves per CU: 9 at 16.7 KB)
+    static constexpr int kTotal = SINGLE ? kIn : (AFFINE ? kOutF + geo::kGroups * kRing * 4 : kInF);      // (LDS bounds the waves per CU: 9 at 16.7 KB, 12 at 12.6)
 };
 
 // Columns [c_lo, c_hi] swept by strip s.  c_lo is a multiple of 4 (16-byte ring accesses).
@@ -119,12 +119,14 @@ __host__ __device__ inline void strip_columns(int s, int R, int F, int pad_rows,
 // packed add with the clamp modifier and the cell is a three-operand maximum: add, max3, add-clamp per packed register
 // instead of add, max, sub, max, max (score_kernel's kGapSymF16).  What routes here: short reads against a reference too
 // long for the resident kernels' LDS.
-template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false, bool F16 = false>
+// SINGLE (the read fits ONE strip: short reads routed here for their reference's length): nothing crosses strips -- no
+// boundary rings in LDS (16.7 -> 12.6 KB per wave: 12 waves per CU instead of 9), no ring read / write per step.
+template <int G, int K, int ALG, bool SYM, bool WIDE, bool AFFINE = false, bool F16 = false, bool SINGLE = false>
 __global__ void __launch_bounds__(64, G == 64 ? 3 : 1)
 score_long_kernel(const LongArgs args) {
     static_assert(!F16 || (ALG == kAlgSW && SYM && !WIDE && !AFFINE), "half-float cells: Smith-Waterman, one gap score, packed");
     using geo = Geo<G, K>;
-    using lay = LongLds<G, K, AFFINE>;
+    using lay = LongLds<G, K, AFFINE, SINGLE>;
     using ops = Cell<WIDE>;
     using cell_t = typename ops::T;
     static_assert(kPhase >= G - 1, "a phase must cover the pipeline skew");
@@ -235,8 +237,10 @@ score_long_kernel(const LongArgs args) {
             // row above: previous lane of the group; for the first lane the previous strip's bottom row
             // (one instruction: the shift writes every lane that has a lane before it -- G = 64: all but lane 0, which keeps
             // the "old" operand, the ring's value; narrower groups select)
-            const unsigned from_ring = *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
-            if constexpr (G == kWave) {
+            const unsigned from_ring = SINGLE ? 0u : *(lds_cu32 *)(in_base + (((c_lo + t) & (kRing - 1)) << 2));
+            if constexpr (SINGLE && G == 16) {              // (row_shr:1: the group's first lane reads 0, the border)
+                up0 = ops::from_bits((unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x111, 0xF, 0xF, true));
+            } else if constexpr (G == kWave) {
                 up0 = ops::from_bits((unsigned)__builtin_amdgcn_update_dpp((int)from_ring, (int)ops::bits(h_last), 0x138, 0xF, 0xF, false));
             } else {
                 const unsigned from_lane = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ops::bits(h_last), 0x138, 0xF, 0xF, true);
@@ -244,7 +248,7 @@ score_long_kernel(const LongArgs args) {
             }
             cell_t fup0 = border_f;
             if constexpr (AFFINE) {
-                const unsigned f_ring = *(lds_cu32 *)(in_base_f + (((c_lo + t) & (kRing - 1)) << 2));
+                const unsigned f_ring = SINGLE ? border_f_bits : *(lds_cu32 *)(in_base_f + (((c_lo + t) & (kRing - 1)) << 2));
                 if constexpr (G == kWave) {
                     fup0 = ops::from_bits((unsigned)__builtin_amdgcn_update_dpp((int)f_ring, (int)ops::bits(f_last), 0x138, 0xF, 0xF, false));
                 } else {
@@ -401,8 +405,10 @@ score_long_kernel(const LongArgs args) {
                 }
                 h_last = h;
                 if (l == G - 1) {
-                    out_grp[j & (kRing - 1)] = ops::bits(h);               // bottom row of the strip
-                    if constexpr (AFFINE) out_grp_f[j & (kRing - 1)] = ops::bits(f_last);
+                    if constexpr (!SINGLE) {
+                        out_grp[j & (kRing - 1)] = ops::bits(h);           // bottom row of the strip
+                        if constexpr (AFFINE) out_grp_f[j & (kRing - 1)] = ops::bits(f_last);
+                    }
                     if (ALG == kAlgNW) row_best = ops::mx(row_best, h);
                 }
             }
@@ -426,6 +432,7 @@ score_long_kernel(const LongArgs args) {
 #pragma unroll
                 for (int x = 0; x < 8; ++x) pre_base[x] = (c0 + x < F) ? src[c0 + x] : (unsigned char)0;
             }
+            if constexpr (SINGLE) return;
             const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;   // lane -> group lane/16, four columns
             pre_brow_valid = g < geo::kGroups && s > 0 && col + 4 <= args.row_dwords;
             if (pre_brow_valid) {       // L2-served load: the same addresses were read two strips ago and rewritten since
@@ -449,6 +456,7 @@ score_long_kernel(const LongArgs args) {
                             (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
                     }
                 }
+                if constexpr (SINGLE) return;
                 const int g = lane / 16, col = c_lo + kLead + t0 + (lane % 16) * 4;
                 if (g >= geo::kGroups) return;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -489,7 +497,7 @@ score_long_kernel(const LongArgs args) {
                 codes[(p / 2) * (lay::kCodeRing * 2) + (p & 1) + (col & (lay::kCodeRing - 1)) * 2] =
                     (unsigned char)((c >= 1 && c <= 4) ? (c - 1) * geo::kPairs + p : geo::kZeroSlab);
             }
-            if (lane < geo::kGroups * kLead) {
+            if (!SINGLE && lane < geo::kGroups * kLead) {
                 const int g = lane / kLead, bc = c_lo + (lane % kLead);
                 unsigned v = 0u, vf = border_f_bits;
                 if (s > 0 && bc < args.row_dwords && bc >= p_lo && bc <= p_hi) {
@@ -535,7 +543,7 @@ score_long_kernel(const LongArgs args) {
         }
         // ---- drain the last two phases of the outgoing row ----
         __syncthreads();
-        if (s + 1 < args.strips) {
+        if (!SINGLE && s + 1 < args.strips) {
             const int phases = (steps + kPhase - 1) / kPhase;
             const int g = lane / 16;
             for (int ph = phases - 2 < 0 ? 0 : phases - 2; ph < phases; ++ph) {
