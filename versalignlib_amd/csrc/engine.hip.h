@@ -317,6 +317,7 @@ public:
     // score_alignments(SW, linear gaps, band_width > 0) on the block chain; false: not applicable here (strips run instead)
     bool score_band_device(long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores, hipStream_t stream);
     bool band_chain_in_use() const;
+    bool long_single_strip(bool wide) const;
 
     // Long sequences: strips of kLongG*kLongK rows, boundary rows through an HBM scratch.
     void score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,

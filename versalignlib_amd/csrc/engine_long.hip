@@ -186,6 +186,11 @@ bool Engine::band_chain_in_use() const {
     return !no_band_chain_ && band_width_ > 0 && (band_plan_width_ == band_width_ ? band_plan_.usable : make_band_plan().usable);
 }
 
+// One 160-row strip, packed cells, no band: the long-read instances that keep nothing in HBM between launches.
+bool Engine::long_single_strip(bool wide) const {
+    return R_ <= kLongG * kLongK && !wide && band_width_ == 0 && !dbg_.on("no_single_strip");
+}
+
 void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, const uint8_t *d_refs, int16_t *d_scores,
                        hipStream_t stream, bool wide) {
     if (band_width_ > 0 && alg != kAlgSW)
@@ -216,7 +221,8 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
     long long chunk = (long long)((8ull << 30) / bytes_per_wave) * ppw;
     chunk = std::max<long long>(ppw, std::min(chunk, (n + ppw - 1) / ppw * ppw));
     const long long waves = chunk / ppw;
-    if ((size_t)waves * bytes_per_wave > brow_bytes_) {
+    const bool single_strip = long_single_strip(wide);       // (no boundary rows: nothing to allocate, nothing shared between launches)
+    if (!single_strip && (size_t)waves * bytes_per_wave > brow_bytes_) {
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
         if (d_brow_) (void)hipFree(d_brow_);
         d_brow_ = nullptr;
@@ -232,7 +238,7 @@ void Engine::score_long_device(int alg, long long n, const uint8_t *d_reads, con
         fn = (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, true>;
     int long_lds = geo.lds[sc_.affine ? 1 : 0];
     // a read of ONE strip (short reads sent here for their reference's length): the instances without boundary rings
-    if (&geo == &kLongStrips && a.strips == 1 && !wide && band_width_ == 0 && !dbg_.on("no_single_strip")) {
+    if (single_strip) {
         static const void *const single[2][2][2] = {
             {{(const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, false, false, false, false, true>,
               (const void *)&score_long_kernel<kLongG, kLongK, kAlgSW, true, false, false, false, true>},

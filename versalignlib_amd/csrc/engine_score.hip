@@ -124,7 +124,9 @@ void Engine::score_host(int opt, int n, const char *const *reads, const char *co
     // Long reads on row strips: their launches follow one another on one stream (the strips' boundary rows are one scratch) and
     // a 48 MB chunk of 10 kbp pairs is 1 200 waves for 3 500 resident ones -- each launch runs at a third of the device.
     // Chunks of up to 192 MB there (the banded block chain needs no scratch: its small chunks run side by side instead).
-    const bool strips_in_turn = plan_.long_mode && !(band_width_ > 0 && alg == kAlgSW && band_chain_in_use());
+    const bool wide_cells = score_width_ == 32 || (score_width_ == 0 && !int16_range_ok(alg));
+    const bool scratch_free = (band_width_ > 0 && alg == kAlgSW && band_chain_in_use()) || (plan_.long_mode && long_single_strip(wide_cells));
+    const bool strips_in_turn = plan_.long_mode && !scratch_free;
     const size_t chunk_bytes = strips_in_turn && !dbg_.on("chunk_bytes") ? std::max<size_t>(score_chunk_bytes_, 192u << 20) : score_chunk_bytes_;
     long long chunk = per_pair ? (long long)(chunk_bytes / per_pair) : n;
     chunk = whole_rounds(chunk);
@@ -159,8 +161,8 @@ void Engine::score_host(int opt, int n, const char *const *reads, const char *co
                         (ragged_ == 2 || sampled_cell_fraction(reads, refs, n) < 0.67);
     // (the banded block chain keeps nothing in HBM between its steps: its chunks may run side by side on the slots' streams --
     // a chunk of 2 400 pairs of 10 kbp fills 600 of the 4 096 resident waves and takes a launch's latency whatever its size)
-    const bool band_chain = band_width_ > 0 && alg == kAlgSW && band_chain_in_use();
-    const bool shared_scratch = !band_chain && (plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg));
+    // ... and so do the single-strip instances of the long-read kernel (short reads against a long reference)
+    const bool shared_scratch = !scratch_free && (plan_.long_mode || score_width_ == 32 || !int16_range_ok(alg));
     host_stats_ = HostStats{};
     auto drain = [&](int s) {
         if (slot_pending_[s] <= 0) return;
