@@ -268,18 +268,16 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             const int pos = row0 + rr;
             rd[i] = (pos >= 0 && pos < R) ? reads[(pair0 + ps) * R + pos] : (unsigned char)0;
         }
-        // ---- raw refs into the (not yet built) profile area ----
-        ref_lo = pair0 * F;
-        stage_span(prof, refs, ref_lo, pair_end * F, lane);
         if (FIND_BAD && lane < geo::kPairs) {
             first_bad[2 * lane] = R;
             first_bad[2 * lane + 1] = F;
         }
     }
-    __syncthreads();
-    const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
 
     // ---- reference bases -> profile slab of the pair (class * kPairs + pair, or the zero slab) ----
+    // One lane group after the other: the group's two raw references are staged in the (not yet built) profile area -- 2 F
+    // bytes instead of the wave's 2 F x groups (round 4: that staging, not the tables, was what a long reference cost first:
+    // 150 x 4 000 on 16 x 10 needs 44 KB instead of 65) -- and turned into the slab numbers of its columns.
     int cols_used = 0;
     if (live) {
         // the sweep prefetches the codes of the next columns unconditionally: pad both ends
@@ -289,13 +287,18 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             unsigned char *dst = refc + g * refc_stride + 2 * col;
             dst[0] = dst[1] = (unsigned char)geo::kZeroSlab;
         }
-        // one lane group after the other (no division by the runtime F), both slab numbers in one store
+    }
 #pragma unroll
-        for (int g = 0; g < geo::kGroups; ++g) {
-            int pa = 2 * g, pb = 2 * g + 1;
-            pa = pa > last ? last : pa;
-            pb = pb > last ? last : pb;
-            const unsigned char *raw_a = prof + ref_skew + pa * F, *raw_b = prof + ref_skew + pb * F;
+    for (int g = 0; g < geo::kGroups; ++g) {
+        int pa = 2 * g, pb = 2 * g + 1;
+        pa = pa > last ? last : pa;
+        pb = pb > last ? last : pb;
+        const long long ref_lo = (pair0 + pa) * F;
+        if (live) stage_span(prof, refs, ref_lo, (pair0 + pb + 1) * F, lane);
+        __syncthreads();
+        if (live) {
+            const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
+            const unsigned char *raw_a = prof + ref_skew, *raw_b = prof + ref_skew + (pb - pa) * F;
             unsigned char *codes_g = refc + g * refc_stride + 2 * kCodePad;
             for (int j = lane; j < F; j += kWave) {
                 const int ca = base_class(raw_a[j]);
@@ -312,8 +315,8 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
                 }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- query profile: slab[class * kPairs + pair][lane rows] = S(read base of the row, class) ----
     if (live) {
@@ -870,7 +873,7 @@ template <int G, int K>
 inline WaveLds wave_lds(int R, int F) {
     using geo = Geo<G, K>;
     WaveLds w;
-    const int raw_refs = ((geo::kPairs * F + 16 + 15) / 16) * 16;    // staged raw, then overwritten
+    const int raw_refs = ((2 * F + 16 + 15) / 16) * 16;              // one lane group's two references, staged raw, then overwritten
     w.prof_area = geo::kProfBytes > raw_refs ? geo::kProfBytes : raw_refs;
     w.prof_area = ((w.prof_area + 15) / 16) * 16;
     w.refc_stride = ((2 * (F + 2 * kCodePad) + 15) / 16) * 16;
