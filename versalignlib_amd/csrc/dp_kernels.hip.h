@@ -288,17 +288,26 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
             dst[0] = dst[1] = (unsigned char)geo::kZeroSlab;
         }
     }
+    // (where all the wave's references fit the profile area anyway -- 8 x 500 bytes in 11.6 KB -- they are staged in one go:
+    // one barrier instead of two per lane group, 1.5 % of the 150 x 500 sweep)
+    const bool whole = geo::kPairs * F + 32 <= prof_area;
+    if (whole) {
+        if (live) stage_span(prof, refs, pair0 * F, pair_end * F, lane);
+        __syncthreads();
+    }
 #pragma unroll
     for (int g = 0; g < geo::kGroups; ++g) {
         int pa = 2 * g, pb = 2 * g + 1;
         pa = pa > last ? last : pa;
         pb = pb > last ? last : pb;
-        const long long ref_lo = (pair0 + pa) * F;
-        if (live) stage_span(prof, refs, ref_lo, (pair0 + pb + 1) * F, lane);
-        __syncthreads();
+        const long long ref_lo = whole ? pair0 * F : (pair0 + pa) * F;
+        if (!whole) {
+            if (live) stage_span(prof, refs, ref_lo, (pair0 + pb + 1) * F, lane);
+            __syncthreads();
+        }
         if (live) {
             const int ref_skew = (int)((unsigned long long)(refs + ref_lo) & 15ull);
-            const unsigned char *raw_a = prof + ref_skew, *raw_b = prof + ref_skew + (pb - pa) * F;
+            const unsigned char *raw_a = prof + ref_skew + (whole ? pa * F : 0), *raw_b = raw_a + (pb - pa) * F;
             unsigned char *codes_g = refc + g * refc_stride + 2 * kCodePad;
             for (int j = lane; j < F; j += kWave) {
                 const int ca = base_class(raw_a[j]);
@@ -315,8 +324,9 @@ __device__ __forceinline__ bool wave_setup(const uint8_t *reads, const uint8_t *
                 }
             }
         }
-        __syncthreads();
+        if (!whole) __syncthreads();
     }
+    if (whole) __syncthreads();
 
     // ---- query profile: slab[class * kPairs + pair][lane rows] = S(read base of the row, class) ----
     if (live) {
