@@ -224,6 +224,9 @@ static void traceback(const uint8_t *read, const uint8_t *ref, int R, int F, con
     int k = AL - 2;
     uint8_t p = ptr[(size_t)(rp + 1) * (F + 1) + fp + 1];
     while (p != PTR_START) {
+        /* (a walk that would leave the matrix -- only possible where the int16 cells wrapped, i.e. outside the range this
+         * restatement is meant for -- stops instead of reading and writing out of bounds) */
+        if (k < 0 || ((p != PTR_LEFT) && rp < 0) || ((p != PTR_UP) && fp < 0)) break;
         if (p == PTR_UP)        { row_ref[k] = '-';      row_read[k] = read[rp--]; }
         else if (p == PTR_LEFT) { row_read[k] = '-';     row_ref[k] = ref[fp--];   }
         else                    { row_read[k] = read[rp--]; row_ref[k] = ref[fp--]; }

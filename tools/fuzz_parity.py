@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--first", type=int, default=0, help="skip the cases before this index (they are still drawn)")
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
     ap.add_argument("--big-every", type=int, default=0, help="every K-th case has 40k-300k pairs (0: none)")
     ap.add_argument("--kinds", default="", help="comma-separated shape kinds to draw from (tiny, short, mid, long, longref); default: a mix")
     a = ap.parse_args()
@@ -146,7 +148,9 @@ def main():
     done = 0
     while time.time() - t0 < a.seconds or (a.only >= 0 and i <= a.only):
         c = draw_case(rng, big=a.big_every > 0 and i % a.big_every == a.big_every - 1, kinds=a.kinds.split(",") if a.kinds else None)
-        if a.only < 0 or i == a.only:
+        if (a.only < 0 or i == a.only) and i >= a.first:
+            if a.verbose:
+                print("case %d: %r" % (i, c), flush=True)
             try:
                 err = run_case(c)
             except host.PluginError as e:
