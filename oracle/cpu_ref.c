@@ -41,6 +41,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #ifdef _OPENMP
@@ -216,6 +217,17 @@ static void nw_fill(const uint8_t *read, const uint8_t *ref, int R, int F, int16
     *end_j = last_ref < snap_arg ? last_ref : snap_arg;
 }
 
+/* A traceback that would leave the matrix: the caller asked the int16 restatement for a shape x scoring outside its range
+ * (tests must use the int32 one there).  Said once per process on stderr, counted for vref_walks_left_matrix().        */
+static int g_walks_left = 0;
+static void vref_note_walk_left_matrix(int R, int F) {
+    int first;
+#pragma omp atomic capture
+    first = g_walks_left++;
+    if (first == 0) fprintf(stderr, "oracle/cpu_ref: a traceback left the %d x %d matrix (cells outside the int16 range?)\n", R, F);
+}
+int vref_walks_left_matrix(void) { return g_walks_left; }
+
 static void traceback(const uint8_t *read, const uint8_t *ref, int R, int F, const uint8_t *ptr,
                       int rp, int fp, uint8_t *row_read, uint8_t *row_ref, int16_t idx[4]) {
     const int AL = R + F;
@@ -226,7 +238,10 @@ static void traceback(const uint8_t *read, const uint8_t *ref, int R, int F, con
     while (p != PTR_START) {
         /* (a walk that would leave the matrix -- only possible where the int16 cells wrapped, i.e. outside the range this
          * restatement is meant for -- stops instead of reading and writing out of bounds) */
-        if (k < 0 || ((p != PTR_LEFT) && rp < 0) || ((p != PTR_UP) && fp < 0)) break;
+        if (k < 0 || ((p != PTR_LEFT) && rp < 0) || ((p != PTR_UP) && fp < 0)) {
+            vref_note_walk_left_matrix(R, F);
+            break;
+        }
         if (p == PTR_UP)        { row_ref[k] = '-';      row_read[k] = read[rp--]; }
         else if (p == PTR_LEFT) { row_read[k] = '-';     row_ref[k] = ref[fp--];   }
         else                    { row_read[k] = read[rp--]; row_ref[k] = ref[fp--]; }
